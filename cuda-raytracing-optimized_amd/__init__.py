@@ -1,0 +1,416 @@
+"""Host-side mirror of the reference's renderer API, bound to the MI355X-native shared libraries.
+
+The reference's host interface for the render hot path is three ``extern "C"`` functions
+(/root/reference/kernels.h:6-8) called from ``main()`` (/root/reference/main.cpp:94-101,138):
+
+    initRenderer(ksc, cam, &fb, nx, ny, maxDepth); runRenderer(ns, tx, ty); cleanupRenderer();
+
+This module binds exactly those symbols (plus the additive ones of include/rt_api.h) from
+``librt_mi355x.so`` with ctypes, and the host-side scene / BVH / PPM / .ref helpers of
+include/rt_host.h from ``librt_host.so``.  Same names, same argument meaning, same error
+behaviour (a HIP failure prints and ``exit(99)``s the process, /root/reference/kernels.cu:27-38).
+
+There is NO CPU fallback: if ``librt_mi355x.so`` is missing the import of the renderer fails
+loudly (``load_renderer``), and without a GPU ``initRenderer*`` terminates the process the way
+the reference does.  The CPU oracle lives in ``oracle/`` and is never imported from here.
+
+Directory name contains '-' (it mirrors the reference repo's name), so import it through the
+``cuda_raytracing_optimized_amd`` alias module at the repo root.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RENDERER_LIB = os.path.join(_HERE, "librt_mi355x.so")
+HOST_LIB = os.path.join(_HERE, "librt_host.so")
+
+RT_DIFFUSE, RT_METAL, RT_GLASS = 0, 1, 2
+RT_SKY_CONST_GREY, RT_SKY_GRADIENT = 0, 1
+RT_RNG_REFERENCE_STREAM, RT_RNG_COUNTER = 0, 1
+RT_FP_PARITY, RT_FP_FAST = 0, 1
+RT_MAX_DEVICES = 8
+
+# ---------------------------------------------------------------------------------------------
+# ctypes mirrors of include/rt_types.h (layouts identical to /root/reference/helper_structs.h)
+# ---------------------------------------------------------------------------------------------
+
+
+class vec3(C.Structure):
+    _fields_ = [("e", C.c_float * 3)]
+
+
+class camera(C.Structure):
+    _fields_ = [("origin", vec3), ("lower_left_corner", vec3), ("horizontal", vec3), ("vertical", vec3),
+                ("u", vec3), ("v", vec3), ("w", vec3), ("lens_radius", C.c_float)]
+
+
+class sphere(C.Structure):
+    _fields_ = [("center", vec3), ("radius", C.c_float)]
+
+
+class plane(C.Structure):
+    _fields_ = [("norm", vec3), ("point", vec3)]
+
+
+class bbox(C.Structure):
+    _fields_ = [("min", vec3), ("max", vec3)]
+
+
+class triangle(C.Structure):
+    _fields_ = [("v", vec3 * 3), ("texCoords", C.c_float * 6), ("meshID", C.c_ubyte), ("_pad", C.c_ubyte * 3)]
+
+
+class bvh_node(C.Structure):
+    _fields_ = [("a", vec3), ("b", vec3)]
+
+
+class material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", vec3), ("param", C.c_float), ("texId", C.c_int32)]
+
+
+class stexture(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_float)), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class mesh(C.Structure):
+    _fields_ = [("tris", C.POINTER(triangle)), ("numTris", C.c_uint32), ("bvh", C.POINTER(bvh_node)),
+                ("numBvhNodes", C.c_int32), ("bounds", bbox)]
+
+
+class kernel_scene(C.Structure):
+    _fields_ = [("m", C.POINTER(mesh)), ("floor", plane), ("materials", C.POINTER(material)),
+                ("numMaterials", C.c_int32), ("textures", C.POINTER(stexture)), ("numTextures", C.c_int32),
+                ("numPrimitivesPerLeaf", C.c_int32)]
+
+
+class render_options(C.Structure):
+    _fields_ = [("sky", C.c_int32), ("nee", C.c_int32), ("rr", C.c_int32), ("t_min", C.c_float),
+                ("rng", C.c_int32), ("fp", C.c_int32), ("light", sphere), ("lightColor", vec3),
+                ("stripe_rows", C.c_int32), ("num_devices", C.c_int32), ("devices", C.c_int32 * RT_MAX_DEVICES),
+                ("part_rank", C.c_int32), ("part_world", C.c_int32), ("variant", C.c_int32), ("counters", C.c_int32)]
+
+
+class render_stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("samples", C.c_int64),
+                ("num_launches", C.c_int32), ("vgprs", C.c_int32), ("rays", C.c_uint64),
+                ("prim_tests", C.c_uint64), ("node_visits", C.c_uint64)]
+
+
+_SIZES = {vec3: 12, camera: 88, sphere: 16, plane: 24, bbox: 24, triangle: 64, bvh_node: 24, material: 24,
+          stexture: 16, mesh: 56, kernel_scene: 64}
+for _t, _s in _SIZES.items():
+    assert C.sizeof(_t) == _s, (_t, C.sizeof(_t), _s)
+
+# numpy views of the array-of-struct types
+sphere_dtype = np.dtype([("center", np.float32, 3), ("radius", np.float32)])
+material_dtype = np.dtype([("type", np.int32), ("color", np.float32, 3), ("param", np.float32), ("texId", np.int32)])
+triangle_dtype = np.dtype([("v", np.float32, (3, 3)), ("texCoords", np.float32, 6), ("meshID", np.uint8), ("_pad", np.uint8, 3)])
+bvh_node_dtype = np.dtype([("a", np.float32, 3), ("b", np.float32, 3)])
+assert sphere_dtype.itemsize == 16 and material_dtype.itemsize == 24
+assert triangle_dtype.itemsize == 64 and bvh_node_dtype.itemsize == 24
+
+# symbols every library must export (tests check the .so against the headers with these)
+RENDERER_SYMBOLS = ["initRenderer", "runRenderer", "cleanupRenderer", "initRendererSpheres",
+                    "getDefaultRenderOptions", "setRenderOptions", "getRenderStats", "rtDeviceCount", "rtApiVersion"]
+HOST_SYMBOLS = ["rtMakeCamera", "rtRandomFloat", "rtSceneThreeSpheres", "rtSceneRandomSpheres", "rtStaircaseCamera",
+                "rtBuildBvh", "rtLoadBvhFile", "rtSaveBvhFile", "rtFreeMesh", "rtMeshView",
+                "rtSceneStaircaseProcedural", "rtLinearToSRGB", "rtWritePPM", "rtSaveReference", "rtLoadReference", "rtRmse"]
+
+_renderer = None
+_host = None
+
+
+def load_host():
+    """librt_host.so (plain C++; works without a GPU)."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise ImportError(f"{HOST_LIB} is not built: run `make` (or __graft_entry__.build())")
+        h = C.CDLL(HOST_LIB)
+        fp = C.POINTER(C.c_float)
+        h.rtMakeCamera.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(camera)]
+        h.rtMakeCamera.restype = None
+        h.rtRandomFloat.argtypes = [C.POINTER(C.c_uint32)]
+        h.rtRandomFloat.restype = C.c_float
+        h.rtSceneThreeSpheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(camera)]
+        h.rtSceneThreeSpheres.restype = C.c_int
+        h.rtSceneRandomSpheres.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(camera)]
+        h.rtSceneRandomSpheres.restype = C.c_int
+        h.rtStaircaseCamera.argtypes = [C.c_int, C.c_int, C.POINTER(camera)]
+        h.rtStaircaseCamera.restype = None
+        h.rtBuildBvh.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        h.rtBuildBvh.restype = C.c_void_p
+        h.rtLoadBvhFile.argtypes = [C.c_char_p]
+        h.rtLoadBvhFile.restype = C.c_void_p
+        h.rtSaveBvhFile.argtypes = [C.c_void_p, C.c_char_p]
+        h.rtSaveBvhFile.restype = C.c_int
+        h.rtFreeMesh.argtypes = [C.c_void_p]
+        h.rtFreeMesh.restype = None
+        h.rtMeshView.argtypes = [C.c_void_p, C.POINTER(mesh)]
+        h.rtMeshView.restype = C.c_int
+        h.rtSceneStaircaseProcedural.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        h.rtSceneStaircaseProcedural.restype = C.c_int
+        h.rtLinearToSRGB.argtypes = [C.c_float]
+        h.rtLinearToSRGB.restype = C.c_uint32
+        h.rtWritePPM.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        h.rtWritePPM.restype = C.c_int
+        h.rtSaveReference.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        h.rtSaveReference.restype = C.c_int
+        h.rtLoadReference.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        h.rtLoadReference.restype = C.c_int
+        h.rtRmse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        h.rtRmse.restype = C.c_double
+        _host = h
+    return _host
+
+
+def load_renderer():
+    """librt_mi355x.so — the HIP renderer.  Raises ImportError if it is not built: there is no fallback."""
+    global _renderer
+    if _renderer is None:
+        if not os.path.exists(RENDERER_LIB):
+            raise ImportError(f"{RENDERER_LIB} is not built: run `make` (or __graft_entry__.build()); "
+                              "there is no CPU fallback for the render path")
+        r = C.CDLL(RENDERER_LIB)
+        r.initRenderer.argtypes = [kernel_scene, camera, C.POINTER(C.POINTER(vec3)), C.c_int, C.c_int, C.c_int]
+        r.initRenderer.restype = None
+        r.runRenderer.argtypes = [C.c_int, C.c_int, C.c_int]
+        r.runRenderer.restype = None
+        r.cleanupRenderer.argtypes = []
+        r.cleanupRenderer.restype = None
+        r.initRendererSpheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, camera, C.POINTER(C.POINTER(vec3)),
+                                          C.c_int, C.c_int, C.c_int]
+        r.initRendererSpheres.restype = None
+        r.getDefaultRenderOptions.argtypes = [C.POINTER(render_options), C.c_int]
+        r.getDefaultRenderOptions.restype = None
+        r.setRenderOptions.argtypes = [C.POINTER(render_options)]
+        r.setRenderOptions.restype = None
+        r.getRenderStats.argtypes = [C.POINTER(render_stats)]
+        r.getRenderStats.restype = None
+        r.rtDeviceCount.argtypes = []
+        r.rtDeviceCount.restype = C.c_int
+        r.rtApiVersion.argtypes = []
+        r.rtApiVersion.restype = C.c_int
+        _renderer = r
+    return _renderer
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side helpers (scene set-up; what main.cpp / staircase_scene.h do before initRenderer)
+# ---------------------------------------------------------------------------------------------
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def make_camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist):
+    """camera::camera, /root/reference/helper_structs.h:194-207."""
+    cam = camera()
+    load_host().rtMakeCamera(_f3(lookfrom), _f3(lookat), _f3(vup), vfov, aspect, aperture, focus_dist, C.byref(cam))
+    return cam
+
+
+def scene_three_spheres(nx, ny):
+    """C1 of SURVEY.md §8d. Returns (spheres, materials, camera)."""
+    sp = np.zeros(3, sphere_dtype)
+    mt = np.zeros(3, material_dtype)
+    cam = camera()
+    n = load_host().rtSceneThreeSpheres(sp.ctypes.data, mt.ctypes.data, 3, nx, ny, C.byref(cam))
+    assert n == 3
+    return sp, mt, cam
+
+
+def scene_random_spheres(nx, ny, seed=0):
+    """C2/C3/C5 of SURVEY.md §8d: 488 spheres. Returns (spheres, materials, camera)."""
+    cap = 488
+    sp = np.zeros(cap, sphere_dtype)
+    mt = np.zeros(cap, material_dtype)
+    cam = camera()
+    n = load_host().rtSceneRandomSpheres(seed, sp.ctypes.data, mt.ctypes.data, cap, nx, ny, C.byref(cam))
+    assert n == cap, n
+    return sp, mt, cam
+
+
+def staircase_camera(nx, ny):
+    cam = camera()
+    load_host().rtStaircaseCamera(nx, ny, C.byref(cam))
+    return cam
+
+
+class HostMesh:
+    """Owns a BVH'd mesh built/loaded by librt_host.so; `.view` is an rt_mesh for kernel_scene.m."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("mesh build/load failed")
+        self._h = C.c_void_p(handle)
+        self.view = mesh()
+        self.nppl = load_host().rtMeshView(self._h, C.byref(self.view))
+
+    @classmethod
+    def build(cls, tris, nppl=5):
+        tris = np.ascontiguousarray(tris, dtype=triangle_dtype)
+        return cls(load_host().rtBuildBvh(tris.ctypes.data, len(tris), nppl))
+
+    @classmethod
+    def load(cls, path):
+        return cls(load_host().rtLoadBvhFile(os.fsencode(path)))
+
+    def save(self, path):
+        return load_host().rtSaveBvhFile(self._h, os.fsencode(path))
+
+    @property
+    def tris(self):
+        return np.ctypeslib.as_array(C.cast(self.view.tris, C.POINTER(C.c_ubyte)), (self.view.numTris * 64,)).view(triangle_dtype)
+
+    @property
+    def bvh(self):
+        return np.ctypeslib.as_array(C.cast(self.view.bvh, C.POINTER(C.c_ubyte)), (self.view.numBvhNodes * 24,)).view(bvh_node_dtype)
+
+    def close(self):
+        if self._h:
+            load_host().rtFreeMesh(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def scene_staircase_procedural(detail=1):
+    """Procedural stand-in for the absent staircase asset. Returns (triangles, materials[20])."""
+    h = load_host()
+    mats = np.zeros(20, material_dtype)
+    need = h.rtSceneStaircaseProcedural(detail, None, 0, mats.ctypes.data)
+    n = -need if need < 0 else need
+    tris = np.zeros(n, triangle_dtype)
+    got = h.rtSceneStaircaseProcedural(detail, tris.ctypes.data, n, mats.ctypes.data)
+    assert got == n, (got, n)
+    return tris, mats
+
+
+def make_kernel_scene(host_mesh, materials, textures=()):
+    """setup_kernel_scene, /root/reference/staircase_scene.h:166-184. Returns (kernel_scene, keepalive)."""
+    materials = np.ascontiguousarray(materials, dtype=material_dtype)
+    ks = kernel_scene()
+    ks.m = C.pointer(host_mesh.view)
+    ks.materials = C.cast(materials.ctypes.data, C.POINTER(material))
+    ks.numMaterials = len(materials)
+    tex_arr = (stexture * max(1, len(textures)))()
+    keep = [materials, tex_arr, host_mesh]
+    for k, t in enumerate(textures):
+        t = np.ascontiguousarray(t, dtype=np.float32)       # (height, width, 3)
+        keep.append(t)
+        tex_arr[k].data = t.ctypes.data_as(C.POINTER(C.c_float))
+        tex_arr[k].height, tex_arr[k].width = t.shape[0], t.shape[1]
+    ks.textures = tex_arr if textures else None
+    ks.numTextures = len(textures)
+    ks.numPrimitivesPerLeaf = host_mesh.nppl
+    return ks, keep
+
+
+# ---------------------------------------------------------------------------------------------
+# renderer API (same names as the C symbols)
+# ---------------------------------------------------------------------------------------------
+
+_state = {"fb": None, "nx": 0, "ny": 0, "keep": None}
+
+
+def _fb_view(fbp, nx, ny):
+    arr = np.ctypeslib.as_array(C.cast(fbp, C.POINTER(C.c_float)), (ny, nx, 3))
+    return arr
+
+
+def initRenderer(ksc, cam, nx, ny, maxDepth, keepalive=None):
+    """extern "C" initRenderer (/root/reference/kernels.h:6). Returns the framebuffer as a (ny, nx, 3) float32 view."""
+    r = load_renderer()
+    fbp = C.POINTER(vec3)()
+    r.initRenderer(ksc, cam, C.byref(fbp), nx, ny, maxDepth)
+    _state.update(fb=_fb_view(fbp, nx, ny), nx=nx, ny=ny, keep=keepalive)
+    return _state["fb"]
+
+
+def initRendererSpheres(spheres, materials, cam, nx, ny, maxDepth):
+    """Additive: sphere-scene initialiser (include/rt_api.h). Returns the framebuffer view."""
+    r = load_renderer()
+    spheres = np.ascontiguousarray(spheres, dtype=sphere_dtype)
+    materials = np.ascontiguousarray(materials, dtype=material_dtype)
+    if len(spheres) != len(materials):
+        raise ValueError("one material per sphere")
+    fbp = C.POINTER(vec3)()
+    r.initRendererSpheres(spheres.ctypes.data, materials.ctypes.data, len(spheres), cam, C.byref(fbp), nx, ny, maxDepth)
+    _state.update(fb=_fb_view(fbp, nx, ny), nx=nx, ny=ny, keep=None)
+    return _state["fb"]
+
+
+def runRenderer(ns, tx=8, ty=8):
+    """extern "C" runRenderer (/root/reference/kernels.h:7); blocking."""
+    load_renderer().runRenderer(ns, tx, ty)
+
+
+def cleanupRenderer():
+    """extern "C" cleanupRenderer (/root/reference/kernels.h:8). The framebuffer view is dead afterwards."""
+    load_renderer().cleanupRenderer()
+    _state.update(fb=None, keep=None)
+
+
+def getDefaultRenderOptions(is_sphere_scene):
+    o = render_options()
+    load_renderer().getDefaultRenderOptions(C.byref(o), 1 if is_sphere_scene else 0)
+    return o
+
+
+def setRenderOptions(opt=None, **kw):
+    """Set options for the following runRenderer calls; keyword arguments override fields of `opt`."""
+    if opt is None:
+        raise ValueError("pass the options struct from getDefaultRenderOptions()")
+    for k, v in kw.items():
+        if k == "devices":
+            opt.num_devices = len(v)
+            for idx, d in enumerate(v):
+                opt.devices[idx] = d
+        else:
+            setattr(opt, k, v)
+    load_renderer().setRenderOptions(C.byref(opt))
+    return opt
+
+
+def getRenderStats():
+    s = render_stats()
+    load_renderer().getRenderStats(C.byref(s))
+    return s
+
+
+def device_count():
+    return load_renderer().rtDeviceCount()
+
+
+# ---------------------------------------------------------------------------------------------
+# output / verification harness (main.cpp:25-60,105-128; staircase_scene.h:22-43)
+# ---------------------------------------------------------------------------------------------
+
+def write_ppm(path, fb):
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    return load_host().rtWritePPM(os.fsencode(path), fb.shape[1], fb.shape[0], fb.ctypes.data)
+
+
+def save_reference(path, fb):
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    return load_host().rtSaveReference(os.fsencode(path), fb.shape[1], fb.shape[0], fb.ctypes.data)
+
+
+def load_reference(path, nx, ny):
+    out = np.zeros((ny, nx, 3), np.float32)
+    rc = load_host().rtLoadReference(os.fsencode(path), out.ctypes.data, nx, ny)
+    return rc, out
+
+
+def rmse(f, g):
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    assert f.shape == g.shape
+    return load_host().rtRmse(f.ctypes.data, g.ctypes.data, f.shape[1], f.shape[0])

@@ -1,0 +1,359 @@
+// rt_kernels_mesh.hip — the render() hot path for TRIANGLE-MESH scenes on gfx950 (wave64).
+//
+// Replaces /root/reference/kernels.cu:535-569 (render), :396-533 (color), :325-360 (hit),
+// :296-323 (hitMesh), :154-224 (hitBvh, DUAL_NODES), :148-152 (pop_bitstack) and :363-393
+// (generateShadowRay), plus the primitive tests of intersections.h:7-41,54-104.
+// Compiled twice (see rt_kernels_spheres.hip): PARITY (-ffp-contract=off, bit-exact vs the
+// oracle up to libm differences in cos/sin) and FAST (FMA contraction).
+//
+// MI355X design:
+//   * one lane = one pixel + its RNG stream; flattened loop with in-lane sample refill;
+//   * BVH child pairs (48 B) are fetched with three plain global_load_dwordx4 from the heap-indexed
+//     node array (the reference used a 1D texture object: kernels.cu:166-173, 590-605); the ~25 MB
+//     working set is L2 / Infinity-Cache resident;
+//   * 1/direction is computed once per ray instead of per box per axis (intersections.h:28) —
+//     the quotient is the same value each time, so this is bit-identical;
+//   * the slab test runs all three axes branch-free: t_min only grows and t_max only shrinks, so a
+//     final `t_max < t_min` equals the reference's per-axis early-out;
+//   * triangles are 64-byte records read as four dwordx4.
+#include "rt_device.h"
+#include "rt_params.h"
+
+#include <float.h>
+
+using namespace rtd;
+
+#if defined(RT_MODE_PARITY)
+#define RT_LAUNCH_NAME rt_launch_mesh_parity
+#elif defined(RT_MODE_FAST)
+#define RT_LAUNCH_NAME rt_launch_mesh_fast
+#else
+#error "define RT_MODE_PARITY or RT_MODE_FAST"
+#endif
+
+namespace {
+
+constexpr int kWavesPerWg = 4;
+constexpr int kThreads = 64 * kWavesPerWg;
+
+__device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
+    const int stripe = lr / pt.stripe_rows;
+    return (stripe * pt.world + pt.rank) * pt.stripe_rows + (lr - stripe * pt.stripe_rows);
+}
+
+struct Ray {
+    f3 o, d, inv;       // origin, unit direction, 1/direction
+};
+
+__device__ __forceinline__ Ray make_ray(f3 o, f3 dir) {     // ray.h:9 + the hoisted invD of intersections.h:28
+    Ray r;
+    r.o = o;
+    r.d = unit(dir);
+    r.inv = F3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    return r;
+}
+
+// one axis of the slab test, intersections.h:27-36
+__device__ __forceinline__ void slab(float bmin, float bmax, float o, float invD, float& t_min, float& t_max) {
+    float t0 = (bmin - o) * invD;
+    float t1 = (bmax - o) * invD;
+    if (invD < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+}
+
+__device__ __forceinline__ float hit_bbox_dist(f3 bmin, f3 bmax, const Ray& r, float t_max) {  // intersections.h:25-41
+    float t_min = 0.001f;
+    slab(bmin.x, bmax.x, r.o.x, r.inv.x, t_min, t_max);
+    slab(bmin.y, bmax.y, r.o.y, r.inv.y, t_min, t_max);
+    slab(bmin.z, bmax.z, r.o.z, r.inv.z, t_min, t_max);
+    return (t_max < t_min) ? FLT_MAX : t_min;
+}
+
+// The early-out of the reference matters for ONE thing: a NaN produced on a later axis (0 * inf)
+// can only appear after an earlier axis already failed... it cannot un-fail the test, because NaN
+// compares false and leaves t_min/t_max unchanged.  So the branch-free form is exact.
+__device__ __forceinline__ bool hit_bbox(f3 bmin, f3 bmax, const Ray& r, float t_max) {        // intersections.h:7-23
+    return hit_bbox_dist(bmin, bmax, r, t_max) != FLT_MAX;
+}
+
+struct Tri { f3 v0, v1, v2; float tc[6]; int meshID; };
+
+__device__ __forceinline__ Tri load_tri(const rt_triangle* tris, uint32_t id) {
+    const float4* p = reinterpret_cast<const float4*>(tris + id);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Tri t;
+    t.v0 = F3(a.x, a.y, a.z); t.v1 = F3(a.w, b.x, b.y); t.v2 = F3(b.z, b.w, c.x);
+    t.tc[0] = c.y; t.tc[1] = c.z; t.tc[2] = c.w; t.tc[3] = d.x; t.tc[4] = d.y; t.tc[5] = d.z;
+    t.meshID = (int)(__float_as_uint(d.w) & 0xFFu);
+    return t;
+}
+
+// triangleHit, intersections.h:54-83.  `1.0 / a` there is a double divide narrowed to float, which
+// equals the correctly rounded float quotient (53 >= 2*24+2), so 1.0f / a is bit-identical.
+__device__ __forceinline__ float triangle_hit(f3 v0, f3 v1, f3 v2, const Ray& r, float t_min, float t_max, float& hitU, float& hitV) {
+    const float EPS = 0.0000001f;
+    const f3 edge1 = v1 - v0;
+    const f3 edge2 = v2 - v0;
+    const f3 h = cross(r.d, edge2);
+    const float a = dot(edge1, h);
+    if (a > -EPS && a < EPS) return FLT_MAX;
+    const float f = 1.0f / a;
+    const f3 s = r.o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return FLT_MAX;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(r.d, q);
+    if (v < 0.0f || u + v > 1.0f) return FLT_MAX;
+    const float t = f * dot(edge2, q);
+    if (t > t_min && t < t_max) { hitU = u; hitV = v; return t; }
+    return FLT_MAX;
+}
+
+__device__ __forceinline__ float sphere_hit(f3 center, float radius, const Ray& r, float t_min, float t_max) {   // intersections.h:85-104
+    const f3 oc = r.o - center;
+    const float a = dot(r.d, r.d);
+    const float b = dot(oc, r.d);
+    const float c = dot(oc, oc) - radius * radius;
+    const float discriminant = b * b - a * c;
+    if (discriminant > 0) {
+        const float sq = __fsqrt_rn(discriminant);
+        float temp = (-b - sq) / a;
+        if (temp < t_max && temp > t_min) return temp;
+        temp = (-b + sq) / a;
+        if (temp < t_max && temp > t_min) return temp;
+    }
+    return FLT_MAX;
+}
+
+struct TravStats { uint32_t nodes, tests; };
+
+// hitBvh (DUAL_NODES), kernels.cu:154-224
+__device__ __forceinline__ float hit_bvh(const RtMeshParams& P, const Ray& r, float t_min, float t_max, bool is_shadow,
+                                         uint32_t& triId, float& hu, float& hv, TravStats& st) {
+    int idx = 1;
+    float closest = t_max;
+    uint32_t bitStack = 1;
+    while (idx) {
+        if ((uint32_t)idx < P.first_leaf) {
+            const int idx2 = idx << 1;
+            const float4* n = P.bvh4 + (size_t)idx * 3;
+            const float4 na = n[0], nb = n[1], nc = n[2];
+            st.nodes++;
+            const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), r, closest);
+            const bool traverseLeft = leftHit < closest;
+            const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), r, closest);
+            const bool traverseRight = rightHit < closest;
+            const bool swap = rightHit < leftHit;
+            if (traverseLeft && traverseRight) {
+                idx = idx2 + (swap ? 1 : 0);
+                bitStack = (bitStack << 1) + 1;
+            } else if (traverseLeft || traverseRight) {
+                idx = idx2 + (swap ? 1 : 0);
+                bitStack = bitStack << 1;
+            } else {
+                const int m = __ffs((int)bitStack) - 1;              // pop_bitstack, kernels.cu:148-152
+                bitStack = (bitStack >> m) ^ 1u;
+                idx = (idx >> m) ^ 1;
+            }
+        } else {
+            const uint32_t first = ((uint32_t)idx - P.first_leaf) * P.nppl;
+            for (uint32_t i = 0; i < P.nppl; i++) {
+                const float4* p = reinterpret_cast<const float4*>(P.tris + first + i);
+                const float4 a = p[0], b = p[1];
+                if (isinf(a.x)) break;                               // kernels.cu:202 sentinel
+                const float cx = p[2].x;
+                float u, v;
+                st.tests++;
+                const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), r, t_min, closest, u, v);
+                if (hitT < closest) {
+                    if (is_shadow) return 0.0f;
+                    closest = hitT;
+                    triId = first + i;
+                    hu = u; hv = v;
+                }
+            }
+            const int m = __ffs((int)bitStack) - 1;
+            bitStack = (bitStack >> m) ^ 1u;
+            idx = (idx >> m) ^ 1;
+        }
+    }
+    return closest;
+}
+
+// hitMesh, kernels.cu:296-323
+__device__ __forceinline__ float hit_mesh(const RtMeshParams& P, const Ray& r, float t_min, float t_max, bool is_shadow,
+                                          uint32_t& triId, float& hu, float& hv, TravStats& st) {
+    if (!hit_bbox(ld3(P.bounds.min), ld3(P.bounds.max), r, t_max)) return FLT_MAX;
+    return hit_bvh(P, r, t_min, t_max, is_shadow, triId, hu, hv, st);
+}
+
+template <int VARIANT>
+__global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) {
+    __shared__ float s_fb[kThreads * 3];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * kWavesPerWg + wave) * 8;
+    const int lr0 = blockIdx.y * 8;
+    const int i = i0 + (lane & 7);
+    const int lr = lr0 + (lane >> 3);
+    const bool valid = (i < P.nx) && (lr < P.part.local_rows);
+    const int j = global_row(P.part, lr);
+    const uint32_t pixelId = (uint32_t)(j * P.nx + i);
+
+    const float eps = P.t_min;
+    const f3 lightC = ld3(P.light.center);
+    const float lightR = P.light.radius;
+
+    uint32_t rng = pixel_seed(pixelId);
+    f3 col = F3(0, 0, 0);
+    f3 org = F3(0, 0, 0), dir = F3(0, 0, 1), atten = F3(1, 1, 1), pcolor = F3(0, 0, 0);
+    int bounce = 0;
+    bool inside = false, specular = false;
+    int s = 0;
+    TravStats st = { 0, 0 };
+    uint32_t nrays = 0, nshadow = 0;
+
+    auto start_sample = [&]() {                                      // kernels.cu:549-555, 397-398
+        if (P.rng_mode == RT_RNG_COUNTER) rng = sample_seed(pixelId, (uint32_t)s);
+        const float u = ((float)i + rnd(rng)) / (float)P.nx;
+        const float v = ((float)j + rnd(rng)) / (float)P.ny;
+        f3 d;
+        get_ray(P.cam, u, v, rng, org, d);
+        dir = unit(d);
+        atten = F3(1.0f, 1.0f, 1.0f);
+        pcolor = F3(0, 0, 0);
+        bounce = 0;
+        inside = false;
+        specular = false;
+    };
+
+    bool active = valid && (P.ns > 0);
+    if (active) start_sample();
+
+    while (active) {
+        // ---- hit(context, p, FLT_MAX, false, inters), kernels.cu:325-360
+        const Ray r = make_ray(org, dir);
+        uint32_t triId = 0;
+        float hu = 0.0f, hv = 0.0f;
+        nrays++;
+        const float t = hit_mesh(P, r, eps, FLT_MAX, false, triId, hu, hv, st);
+        bool path_done = false;
+        if (t < FLT_MAX) {
+            const Tri tri = load_tri(P.tris, triId);                 // kernels.cu:334
+            f3 normal = unit(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+            const float w0 = 1 - hu - hv;
+            const float tcu = (hu * tri.tc[2] + hv * tri.tc[4] + w0 * tri.tc[0]);
+            const float tcv = (hu * tri.tc[3] + hv * tri.tc[5] + w0 * tri.tc[1]);
+            if (dot(r.d, normal) > 0.0f) normal = -normal;           // kernels.cu:354-355
+
+            const rt_material mat = P.materials[tri.meshID];         // kernels.cu:452-480
+            f3 albedo;
+            if (mat.texId != -1) {
+                const int width = P.tex_width[mat.texId];
+                const int height = P.tex_height[mat.texId];
+                float tu = tcu; tu = tu - floorf(tu);
+                float tv = tcv; tv = tv - floorf(tv);
+                const int tx = (int)((float)(width - 1) * tu);
+                const int ty = (int)((float)(height - 1) * tv);
+                const int tIdx = ty * width + tx;
+                const float* d = P.tex_data[mat.texId];
+                albedo = F3(d[tIdx * 3 + 0], d[tIdx * 3 + 1], d[tIdx * 3 + 2]);
+            } else {
+                albedo = ld3(mat.color);
+            }
+            Scatter sc;
+            material_scatter(sc, t, normal, inside, dir, mat.type, albedo, mat.param, rng);
+            org = org + sc.t * dir;                                  // kernels.cu:485-489
+            dir = sc.wi;
+            atten = atten * sc.throughput;
+            specular = sc.specular;
+            inside = sc.refracted ? !inside : inside;
+
+            if (P.nee && !specular) {                                // generateShadowRay, kernels.cu:363-393
+                const f3 sw = unit(lightC - org);
+                const f3 su = unit(cross(fabsf(sw.x) > 0.01f ? F3(0, 1, 0) : F3(1, 0, 0), sw));
+                const f3 sv = cross(sw, su);
+                const float cosAMax = __fsqrt_rn(1.0f - lightR * lightR / sqlen(org - lightC));
+                if (!isnan(cosAMax)) {
+                    const float eps1 = rnd(rng);
+                    const float eps2 = rnd(rng);
+                    const float cosA = 1.0f - eps1 + eps1 * cosAMax;
+                    const float sinA = __fsqrt_rn(1.0f - cosA * cosA);
+                    const float phi = (float)(2 * M_PI * (double)eps2);
+                    // cosf/sinf of the reference: evaluated in fp64 and rounded once (libm vs OCML differ by ulps otherwise)
+                    const float cphi = (float)cos((double)phi), sphi = (float)sin((double)phi);
+                    const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
+                    const float dotl = dot(l, normal);
+                    if (dotl > 0) {
+                        const f3 shadowDir = unit(l);
+                        const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));
+                        const f3 contrib = (omega * (dotl * (atten * ld3(P.lightColor)))) / (float)M_PI;
+                        const float lightDist = len(lightC - org) - lightR;
+                        const Ray sr = make_ray(org, shadowDir);
+                        uint32_t tid2 = 0; float u2, v2;
+                        nshadow++;
+                        const float ts = hit_mesh(P, sr, eps, lightDist, true, tid2, u2, v2, st);
+                        if (!(ts < lightDist)) pcolor = pcolor + contrib;    // kernels.cu:504-510
+                    }
+                }
+            }
+            if (P.rr && bounce > 3) {                                // kernels.cu:512-527
+                const float mx = max3(atten);
+                if (rnd(rng) > mx) {
+                    path_done = true;
+                } else {
+                    const float kk = 1.0f / mx;
+                    atten = F3(atten.x * kk, atten.y * kk, atten.z * kk);
+                }
+            }
+            bounce++;
+            if (bounce >= P.max_depth) path_done = true;
+        } else if (specular && sphere_hit(lightC, lightR, r, eps, FLT_MAX) < FLT_MAX) {   // kernels.cu:346
+            if (!P.nee) pcolor = pcolor + atten * ld3(P.lightColor);                      // kernels.cu:440-446
+            path_done = true;
+        } else {
+            pcolor = pcolor + atten * sky_color(P.sky, dir);         // kernels.cu:419-425
+            path_done = true;
+        }
+
+        if (path_done) {
+            col = col + pcolor;
+            s++;
+            if (s < P.ns) start_sample();
+            else active = false;
+        }
+    }
+
+    const f3 out = col / (float)P.ns;                                // kernels.cu:568
+    float* my = s_fb + threadIdx.x * 3;
+    my[0] = out.x; my[1] = out.y; my[2] = out.z;
+    __syncthreads();
+    const float* wfb = s_fb + wave * 192;
+    float* fbf = reinterpret_cast<float*>(P.fb);
+#pragma unroll
+    for (int q = lane; q < 192; q += 64) {
+        const int row = q / 24, off = q - row * 24;
+        const int px = i0 + off / 3;
+        const int rr = lr0 + row;
+        if (px < P.nx && rr < P.part.local_rows)
+            fbf[((size_t)rr * P.nx + i0) * 3 + off] = wfb[q];
+    }
+
+    if (P.counters) {
+        atomicAdd(&P.counters->rays, (unsigned long long)nrays);
+        atomicAdd(&P.counters->shadow_rays, (unsigned long long)nshadow);
+        atomicAdd(&P.counters->prim_tests, (unsigned long long)st.tests);
+        atomicAdd(&P.counters->node_visits, (unsigned long long)st.nodes);
+    }
+}
+
+}  // namespace
+
+hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream) {
+    (void)variant;
+    const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
+    hipLaunchKernelGGL(k_render_mesh<0>, grid, dim3(kThreads), 0, stream, p);
+    return hipGetLastError();
+}

@@ -1,0 +1,76 @@
+// rt_params.h — kernel argument blocks and the launch entry points each kernel TU exports.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_types.h"
+
+// Row partition of the image over devices / processes: the image is cut into
+// stripes of `stripe_rows` rows; stripe k belongs to part (k % world).  A device renders its
+// stripes into a COMPACT buffer of `local_rows` rows; local row lr maps to global row
+//   j = ((lr / stripe_rows) * world + rank) * stripe_rows + lr % stripe_rows.
+// Pixel seeds always use the GLOBAL pixel id, so the assembled image does not depend on the partition.
+struct RtPartition {
+    int32_t stripe_rows;
+    int32_t rank;
+    int32_t world;
+    int32_t local_rows;
+};
+
+struct RtCounters {             // device-side, optional
+    unsigned long long rays;
+    unsigned long long prim_tests;
+    unsigned long long node_visits;
+    unsigned long long shadow_rays;
+};
+
+struct RtSphereParams {
+    rt_camera cam;
+    int32_t nx, ny, ns, max_depth;
+    int32_t n;                  // spheres
+    int32_t n_padded;           // multiple of 32 (pad entries can never be hit)
+    const float4* spheres;      // n_padded x (cx, cy, cz, radius)
+    const float4* mat_color;    // n x (r, g, b, param)
+    const int32_t* mat_type;    // n
+    rt_vec3* fb;                // compact framebuffer: local_rows x nx
+    RtPartition part;
+    int32_t sky;
+    int32_t rr;
+    int32_t rng_mode;
+    float   t_min;
+    RtCounters* counters;       // nullptr = off
+};
+
+struct RtMeshParams {
+    rt_camera cam;
+    int32_t nx, ny, ns, max_depth;
+    const rt_triangle* tris;
+    const float4* bvh4;         // heap-indexed nodes viewed as float4 texels: child pair of node i at texels 3i..3i+2
+    uint32_t first_leaf;
+    uint32_t nppl;
+    rt_bbox bounds;
+    const rt_material* materials;
+    const float* const* tex_data;
+    const int32_t* tex_width;
+    const int32_t* tex_height;
+    rt_vec3* fb;
+    RtPartition part;
+    int32_t sky;
+    int32_t nee;
+    int32_t rr;
+    int32_t rng_mode;
+    float   t_min;
+    rt_sphere light;
+    rt_vec3 lightColor;
+    RtCounters* counters;
+};
+
+// LDS the sphere kernel needs for a scene of n spheres with `threads` threads per workgroup.
+size_t rt_sphere_kernel_lds_bytes(int n_padded, int n, int threads);
+
+// Each returns the hipError_t of the launch.  `variant` selects a kernel variant (0 = default).
+hipError_t rt_launch_spheres_parity(const RtSphereParams& p, int variant, hipStream_t stream);
+hipError_t rt_launch_spheres_fast(const RtSphereParams& p, int variant, hipStream_t stream);
+hipError_t rt_launch_mesh_parity(const RtMeshParams& p, int variant, hipStream_t stream);
+hipError_t rt_launch_mesh_fast(const RtMeshParams& p, int variant, hipStream_t stream);

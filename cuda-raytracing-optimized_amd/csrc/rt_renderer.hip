@@ -1,0 +1,417 @@
+// rt_renderer.hip — host runtime behind the C-ABI of include/rt_api.h (librt_mi355x.so).
+//
+// Replaces the host half of /root/reference/kernels.cu: the global RenderContext (:69-145),
+// initRenderer (:571-650), runRenderer (:652-664), cleanupRenderer (:666-680) and check_cuda
+// (:27-38).  Same contract: one global context, synchronous render, void returns, exit(99) on any
+// runtime failure.  MI355X differences:
+//   * the framebuffer handed to the caller is pinned host memory; each device renders into a compact
+//     device buffer and its stripes are gathered with plain hipMemcpy2DAsync (no managed memory
+//     page migration, no RCCL);
+//   * the image can be split into interleaved row stripes over several devices of this process
+//     (options.devices) and/or over several processes (options.part_rank/part_world);
+//   * the BVH is read with plain 16-byte global loads (no texture object);
+//   * the kernel is timed with HIP events on the stream it is launched on (getRenderStats).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_api.h"
+#include "rt_params.h"
+
+namespace {
+
+#define HIP_CHECK(expr) hip_check((expr), #expr, __FILE__, __LINE__)
+
+void hip_check(hipError_t result, const char* func, const char* file, int line) {   // kernels.cu:27-38
+    if (result != hipSuccess) {
+        fprintf(stderr, "HIP error = %s at %s:%d '%s' \n", hipGetErrorString(result), file, line, func);
+        exit(99);
+    }
+}
+
+[[noreturn]] void rt_fail(const char* msg) {
+    fprintf(stderr, "rt error: %s\n", msg);
+    exit(99);
+}
+
+struct DeviceState {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // sphere scene
+    float4* d_spheres = nullptr;
+    float4* d_mat_color = nullptr;
+    int32_t* d_mat_type = nullptr;
+    // mesh scene
+    rt_triangle* d_tris = nullptr;
+    float4* d_bvh = nullptr;
+    rt_material* d_materials = nullptr;
+    std::vector<float*> d_tex;
+    float** d_tex_data = nullptr;
+    int32_t* d_tex_width = nullptr;
+    int32_t* d_tex_height = nullptr;
+    // output
+    rt_vec3* d_fb = nullptr;
+    size_t fb_rows = 0;
+    RtCounters* d_counters = nullptr;
+};
+
+struct RenderContext {
+    bool initialised = false;
+    bool is_spheres = false;
+    int nx = 0, ny = 0, max_depth = 0;
+    rt_camera cam;
+    rt_render_options opt;
+    rt_vec3* h_fb = nullptr;            // pinned, nx*ny, handed to the caller
+    // host copies of the scene (so devices can be (re)configured by setRenderOptions)
+    std::vector<float4> h_spheres;      // padded
+    std::vector<float4> h_mat_color;
+    std::vector<int32_t> h_mat_type;
+    int n_spheres = 0, n_padded = 0;
+    std::vector<rt_triangle> h_tris;
+    std::vector<float4> h_bvh;          // numBvhNodes * 24 B viewed as float4 (padded)
+    int num_bvh_nodes = 0;
+    int nppl = 0;
+    rt_bbox bounds;
+    std::vector<rt_material> h_materials;
+    std::vector<std::vector<float>> h_tex;
+    std::vector<int32_t> h_tex_w, h_tex_h;
+    std::vector<DeviceState> devs;
+    rt_render_stats stats;
+};
+
+RenderContext g_ctx;     // kernels.cu:145: one global context per process
+
+void default_options(rt_render_options* o, int spheres) {
+    memset(o, 0, sizeof *o);
+    o->sky = spheres ? RT_SKY_GRADIENT : RT_SKY_CONST_GREY;     // kernels.cu:419-424
+    o->nee = spheres ? 0 : 1;                                   // kernels.cu:16 SHADOW
+    o->rr = spheres ? 0 : 1;                                    // kernels.cu:14 RUSSIAN_ROULETTE
+    o->t_min = spheres ? 0.001f : 0.01f;                        // kernels.cu:19 EPSILON
+    o->rng = RT_RNG_REFERENCE_STREAM;
+    o->fp = RT_FP_PARITY;
+    o->light.center.e[0] = (float)52.514355;                    // kernels.cu:93
+    o->light.center.e[1] = (float)715.686951;
+    o->light.center.e[2] = (float)-272.620972;
+    o->light.radius = 50.0f;
+    o->lightColor.e[0] = o->lightColor.e[1] = o->lightColor.e[2] = 20.0f;   // kernels.cu:94
+    o->stripe_rows = 8;
+    o->num_devices = 0;                                         // 0 = the process's current HIP device
+    o->part_rank = 0;
+    o->part_world = 1;
+}
+
+void free_device(DeviceState& d) {
+    HIP_CHECK(hipSetDevice(d.device));
+    if (d.stream) HIP_CHECK(hipStreamSynchronize(d.stream));
+    auto fr = [](void* p) { if (p) HIP_CHECK(hipFree(p)); };
+    fr(d.d_spheres); fr(d.d_mat_color); fr(d.d_mat_type);
+    fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
+    for (float* t : d.d_tex) fr(t);
+    fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
+    fr(d.d_fb); fr(d.d_counters);
+    if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
+    if (d.ev_stop) HIP_CHECK(hipEventDestroy(d.ev_stop));
+    if (d.stream) HIP_CHECK(hipStreamDestroy(d.stream));
+    d = DeviceState();
+}
+
+template <typename T>
+T* upload(const std::vector<T>& v) {
+    if (v.empty()) return nullptr;
+    T* p = nullptr;
+    HIP_CHECK(hipMalloc((void**)&p, v.size() * sizeof(T)));
+    HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+
+// Rows of the image owned by partition member `rank` of `world` with stripes of `sr` rows.
+int local_rows_of(int ny, int sr, int rank, int world) {
+    int rows = 0;
+    const int nstripes = (ny + sr - 1) / sr;
+    for (int k = rank; k < nstripes; k += world) rows += std::min(sr, ny - k * sr);
+    return rows;
+}
+
+// (Re)creates the per-device state for the device list in g_ctx.opt.
+void setup_devices() {
+    RenderContext& c = g_ctx;
+    for (DeviceState& d : c.devs) free_device(d);
+    c.devs.clear();
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    int nd = c.opt.num_devices <= 0 ? 1 : c.opt.num_devices;
+    if (nd > RT_MAX_DEVICES) rt_fail("too many devices");
+    int current = 0;
+    HIP_CHECK(hipGetDevice(&current));
+    for (int k = 0; k < nd; k++) {
+        DeviceState d;
+        d.device = (c.opt.num_devices <= 0) ? current : c.opt.devices[k];
+        if (d.device < 0 || d.device >= count) rt_fail("device index out of range");
+        HIP_CHECK(hipSetDevice(d.device));
+        HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&d.ev_start));
+        HIP_CHECK(hipEventCreate(&d.ev_stop));
+        if (c.is_spheres) {
+            d.d_spheres = upload(c.h_spheres);
+            d.d_mat_color = upload(c.h_mat_color);
+            d.d_mat_type = upload(c.h_mat_type);
+        } else {
+            d.d_tris = upload(c.h_tris);
+            d.d_bvh = upload(c.h_bvh);
+            d.d_materials = upload(c.h_materials);
+            const int nt = (int)c.h_tex.size();
+            if (nt > 0) {
+                for (int t = 0; t < nt; t++) d.d_tex.push_back(upload(c.h_tex[t]));
+                std::vector<float*> ptrs(d.d_tex.begin(), d.d_tex.end());
+                d.d_tex_data = upload(ptrs);
+                d.d_tex_width = upload(c.h_tex_w);
+                d.d_tex_height = upload(c.h_tex_h);
+            }
+        }
+        const int world = c.opt.part_world * nd, rank = c.opt.part_rank * nd + k;
+        d.fb_rows = (size_t)local_rows_of(c.ny, c.opt.stripe_rows, rank, world);
+        if (d.fb_rows > 0) HIP_CHECK(hipMalloc((void**)&d.d_fb, d.fb_rows * c.nx * sizeof(rt_vec3)));
+        HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
+        HIP_CHECK(hipMemset(d.d_counters, 0, sizeof(RtCounters)));
+        c.devs.push_back(d);
+    }
+    HIP_CHECK(hipSetDevice(current));
+}
+
+void validate_options(const rt_render_options& o) {
+    if (o.stripe_rows <= 0 || (o.stripe_rows % 8) != 0) rt_fail("stripe_rows must be a positive multiple of 8");
+    if (o.part_world < 1 || o.part_rank < 0 || o.part_rank >= o.part_world) rt_fail("bad part_rank/part_world");
+    if (o.num_devices < 0 || o.num_devices > RT_MAX_DEVICES) rt_fail("bad num_devices");
+    if (!(o.t_min >= 0.0f)) rt_fail("t_min must be >= 0");
+    if (o.sky != RT_SKY_CONST_GREY && o.sky != RT_SKY_GRADIENT) rt_fail("bad sky mode");
+    if (o.rng != RT_RNG_REFERENCE_STREAM && o.rng != RT_RNG_COUNTER) rt_fail("bad rng mode");
+    if (o.fp != RT_FP_PARITY && o.fp != RT_FP_FAST) rt_fail("bad fp mode");
+}
+
+void common_init(const rt_camera& cam, rt_vec3** fb, int nx, int ny, int maxDepth) {
+    RenderContext& c = g_ctx;
+    if (nx <= 0 || ny <= 0 || (long long)nx * ny > (1ll << 30)) rt_fail("bad image size");
+    if (!fb) rt_fail("fb out-parameter is null");
+    c.nx = nx; c.ny = ny;
+    c.max_depth = maxDepth > 255 ? 255 : maxDepth;      // uint8_t bounce, helper_structs.h:58
+    c.cam = cam;
+    HIP_CHECK(hipHostMalloc((void**)&c.h_fb, (size_t)nx * ny * sizeof(rt_vec3), hipHostMallocDefault));   // kernels.cu:578-580
+    memset(c.h_fb, 0, (size_t)nx * ny * sizeof(rt_vec3));
+    *fb = c.h_fb;
+    memset(&c.stats, 0, sizeof c.stats);
+    setup_devices();
+    c.initialised = true;
+}
+
+void cleanup_impl() {
+    RenderContext& c = g_ctx;
+    for (DeviceState& d : c.devs) free_device(d);
+    c.devs.clear();
+    if (c.h_fb) HIP_CHECK(hipHostFree(c.h_fb));
+    c = RenderContext();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtApiVersion(void) { return 1000; }
+
+int rtDeviceCount(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+void getDefaultRenderOptions(rt_render_options* opt, int is_sphere_scene) {
+    if (!opt) return;
+    default_options(opt, is_sphere_scene);
+}
+
+void initRenderer(const rt_kernel_scene sc, const rt_camera cam, rt_vec3** fb, int nx, int ny, int maxDepth) {
+    if (g_ctx.initialised) cleanup_impl();
+    RenderContext& c = g_ctx;
+    if (!sc.m || !sc.m->tris || !sc.m->bvh || !sc.materials) rt_fail("initRenderer: null scene pointers");
+    if (sc.m->numBvhNodes < 4 || (sc.m->numBvhNodes & 1)) rt_fail("initRenderer: numBvhNodes must be even and >= 4");
+    if (sc.numPrimitivesPerLeaf <= 0) rt_fail("initRenderer: numPrimitivesPerLeaf must be positive");
+    const uint32_t first_leaf = (uint32_t)sc.m->numBvhNodes / 2;                               // kernels.cu:614
+    if ((unsigned long long)first_leaf * (unsigned)sc.numPrimitivesPerLeaf > sc.m->numTris)
+        rt_fail("initRenderer: leaves * numPrimitivesPerLeaf exceeds numTris (traversal would read out of bounds)");
+    if (first_leaf > (1u << 30)) rt_fail("initRenderer: BVH deeper than the 32-bit traversal bit-stack");
+    c.is_spheres = false;
+    default_options(&c.opt, 0);
+    c.h_tris.assign(sc.m->tris, sc.m->tris + sc.m->numTris);                                  // kernels.cu:582-583
+    for (const rt_triangle& t : c.h_tris)
+        if (t.meshID >= sc.numMaterials && !std::isinf(t.v[0].e[0])) rt_fail("initRenderer: triangle meshID out of range");
+    c.num_bvh_nodes = sc.m->numBvhNodes;                                                       // kernels.cu:587-605
+    const size_t nfloats = (size_t)c.num_bvh_nodes * 6;
+    c.h_bvh.assign((nfloats + 3) / 4 + 1, make_float4(0, 0, 0, 0));
+    memcpy(c.h_bvh.data(), sc.m->bvh, nfloats * sizeof(float));
+    c.nppl = sc.numPrimitivesPerLeaf;                                                          // kernels.cu:648
+    c.bounds = sc.m->bounds;
+    c.h_materials.assign(sc.materials, sc.materials + sc.numMaterials);                        // kernels.cu:617-618
+    c.h_tex.clear(); c.h_tex_w.clear(); c.h_tex_h.clear();
+    for (int t = 0; t < sc.numTextures; t++) {                                                 // kernels.cu:620-645
+        const rt_stexture& tx = sc.textures[t];
+        if (!tx.data || tx.width <= 0 || tx.height <= 0) rt_fail("initRenderer: bad texture");
+        c.h_tex.emplace_back(tx.data, tx.data + (size_t)tx.width * tx.height * 3);
+        c.h_tex_w.push_back(tx.width);
+        c.h_tex_h.push_back(tx.height);
+    }
+    for (const rt_material& m : c.h_materials)
+        if (m.texId != -1 && (m.texId < 0 || m.texId >= sc.numTextures)) rt_fail("initRenderer: material texId out of range");
+    common_init(cam, fb, nx, ny, maxDepth);
+}
+
+void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials, int n,
+                         const rt_camera cam, rt_vec3** fb, int nx, int ny, int maxDepth) {
+    if (g_ctx.initialised) cleanup_impl();
+    RenderContext& c = g_ctx;
+    if (!spheres || !materials || n <= 0) rt_fail("initRendererSpheres: empty scene");
+    c.is_spheres = true;
+    default_options(&c.opt, 1);
+    c.n_spheres = n;
+    c.n_padded = (n + 31) & ~31;
+    // pad entries: radius 0 far away; additionally the kernel never accepts an index >= n
+    c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));
+    c.h_mat_color.resize(n);
+    c.h_mat_type.resize(n);
+    for (int k = 0; k < n; k++) {
+        c.h_spheres[k] = make_float4(spheres[k].center.e[0], spheres[k].center.e[1], spheres[k].center.e[2], spheres[k].radius);
+        c.h_mat_color[k] = make_float4(materials[k].color.e[0], materials[k].color.e[1], materials[k].color.e[2], materials[k].param);
+        if (materials[k].type < RT_DIFFUSE || materials[k].type > RT_GLASS) rt_fail("initRendererSpheres: bad material type");
+        c.h_mat_type[k] = materials[k].type;
+    }
+    if (rt_sphere_kernel_lds_bytes(c.n_padded, n, 256) > 160 * 1024)
+        rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 4400 spheres)");
+    common_init(cam, fb, nx, ny, maxDepth);
+}
+
+void setRenderOptions(const rt_render_options* opt) {
+    RenderContext& c = g_ctx;
+    if (!c.initialised) rt_fail("setRenderOptions before init");
+    if (!opt) rt_fail("setRenderOptions: null");
+    validate_options(*opt);
+    const rt_render_options old = c.opt;
+    c.opt = *opt;
+    bool relayout = old.stripe_rows != opt->stripe_rows || old.part_rank != opt->part_rank ||
+                    old.part_world != opt->part_world || old.num_devices != opt->num_devices;
+    for (int k = 0; k < RT_MAX_DEVICES && !relayout; k++) relayout = old.devices[k] != opt->devices[k];
+    if (relayout) setup_devices();
+}
+
+void runRenderer(int ns, int tx, int ty) {
+    (void)tx; (void)ty;     // CUDA block shape of the reference (main.cpp:69-70); the wave64 tile is fixed
+    RenderContext& c = g_ctx;
+    if (!c.initialised) rt_fail("runRenderer before init");
+    if (ns <= 0) rt_fail("runRenderer: ns must be positive");
+    const auto t0 = std::chrono::steady_clock::now();
+    int current = 0;
+    HIP_CHECK(hipGetDevice(&current));
+    const int nd = (int)c.devs.size();
+    const int world = c.opt.part_world * nd;
+    const size_t row_bytes = (size_t)c.nx * sizeof(rt_vec3);
+    int64_t samples = 0;
+    int launches = 0;
+
+    for (int k = 0; k < nd; k++) {
+        DeviceState& d = c.devs[k];
+        if (d.fb_rows == 0) continue;
+        HIP_CHECK(hipSetDevice(d.device));
+        RtPartition part;
+        part.stripe_rows = c.opt.stripe_rows;
+        part.rank = c.opt.part_rank * nd + k;
+        part.world = world;
+        part.local_rows = (int)d.fb_rows;
+        if (c.opt.counters) HIP_CHECK(hipMemsetAsync(d.d_counters, 0, sizeof(RtCounters), d.stream));
+        HIP_CHECK(hipEventRecord(d.ev_start, d.stream));
+        if (c.max_depth <= 0) {
+            HIP_CHECK(hipMemsetAsync(d.d_fb, 0, d.fb_rows * row_bytes, d.stream));     // loop of kernels.cu:402 never runs
+        } else if (c.is_spheres) {
+            RtSphereParams p;
+            memset(&p, 0, sizeof p);
+            p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
+            p.n = c.n_spheres; p.n_padded = c.n_padded;
+            p.spheres = d.d_spheres; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
+            p.fb = d.d_fb; p.part = part;
+            p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
+            p.counters = c.opt.counters ? d.d_counters : nullptr;
+            if (c.opt.nee) rt_fail("runRenderer: next-event estimation is only defined for mesh scenes");
+            HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream)
+                                             : rt_launch_spheres_parity(p, c.opt.variant, d.stream));
+            launches++;
+        } else {
+            RtMeshParams p;
+            memset(&p, 0, sizeof p);
+            p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
+            p.tris = d.d_tris; p.bvh4 = d.d_bvh;
+            p.first_leaf = (uint32_t)c.num_bvh_nodes / 2; p.nppl = (uint32_t)c.nppl; p.bounds = c.bounds;
+            p.materials = d.d_materials;
+            p.tex_data = d.d_tex_data; p.tex_width = d.d_tex_width; p.tex_height = d.d_tex_height;
+            p.fb = d.d_fb; p.part = part;
+            p.sky = c.opt.sky; p.nee = c.opt.nee; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
+            p.light = c.opt.light; p.lightColor = c.opt.lightColor;
+            p.counters = c.opt.counters ? d.d_counters : nullptr;
+            HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_mesh_fast(p, c.opt.variant, d.stream)
+                                             : rt_launch_mesh_parity(p, c.opt.variant, d.stream));
+            launches++;
+        }
+        HIP_CHECK(hipEventRecord(d.ev_stop, d.stream));
+
+        // gather: local stripe q (rows of the compact buffer) -> global stripe q*world + rank of the pinned framebuffer
+        const int sr = c.opt.stripe_rows;
+        const size_t stripe_bytes = (size_t)sr * row_bytes;
+        const size_t full = d.fb_rows / sr, rem = d.fb_rows % sr;
+        char* dst0 = reinterpret_cast<char*>(c.h_fb) + (size_t)part.rank * stripe_bytes;
+        const char* src0 = reinterpret_cast<const char*>(d.d_fb);
+        if (full > 0)
+            HIP_CHECK(hipMemcpy2DAsync(dst0, (size_t)world * stripe_bytes, src0, stripe_bytes, stripe_bytes, full,
+                                       hipMemcpyDeviceToHost, d.stream));
+        if (rem > 0)
+            HIP_CHECK(hipMemcpyAsync(dst0 + full * (size_t)world * stripe_bytes, src0 + full * stripe_bytes, rem * row_bytes,
+                                     hipMemcpyDeviceToHost, d.stream));
+        samples += (int64_t)d.fb_rows * c.nx * ns;
+    }
+
+    double kernel_ms = 0.0;
+    rt_render_stats st;
+    memset(&st, 0, sizeof st);
+    for (int k = 0; k < nd; k++) {
+        DeviceState& d = c.devs[k];
+        if (d.fb_rows == 0) continue;
+        HIP_CHECK(hipSetDevice(d.device));
+        HIP_CHECK(hipStreamSynchronize(d.stream));                      // kernels.cu:660-661: blocking
+        float ms = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms, d.ev_start, d.ev_stop));
+        kernel_ms = std::max(kernel_ms, (double)ms);
+        if (c.opt.counters) {
+            RtCounters h;
+            HIP_CHECK(hipMemcpy(&h, d.d_counters, sizeof h, hipMemcpyDeviceToHost));
+            st.rays += h.rays; st.prim_tests += h.prim_tests; st.node_visits += h.node_visits;
+        }
+    }
+    HIP_CHECK(hipSetDevice(current));
+    const auto t1 = std::chrono::steady_clock::now();
+    st.kernel_ms = kernel_ms;
+    st.total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    st.samples = samples;
+    st.num_launches = launches;
+    c.stats = st;
+}
+
+void getRenderStats(rt_render_stats* out) {
+    if (out) *out = g_ctx.stats;
+}
+
+void cleanupRenderer(void) {
+    if (!g_ctx.initialised) return;
+    cleanup_impl();
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+/*
+ * ref_driver.cpp — thin C-ABI shim over the REFERENCE'S OWN header-only hot-path code.
+ * TEST INFRASTRUCTURE ONLY; built only in the container that has /root/reference.
+ *
+ * Nothing from the reference is copied here: its headers are #included from where they lie
+ * (-I/root/reference) and its functions are called as they are.  <cuda_runtime.h>
+ * (helper_structs.h:3) resolves to the NVIDIA header that ships in this image inside
+ * triton (…/triton/backends/nvidia/include); under a plain host compiler it defines
+ * __host__/__device__ to nothing, so no stand-in header is written.
+ *
+ * Built by oracle/Makefile with ROCm's clang++ (-O2 -ffp-contract=off) into
+ * oracle/_ref/libref.so.  clang evaluates the arguments of `vec3(rnd(),rnd(),rnd())`
+ * (rnd.h:23,41) left to right — the order hipcc/clang device code uses and the order the
+ * oracle pins; g++ would draw z,y,x.
+ *
+ * Exports:
+ *   ref_*            one wrapper per reference function on the hot path (same argument meaning
+ *                    as the orc_* function of the same name in rt_oracle.h)
+ *   ref_render_spheres   a single-threaded host loop over pixels and samples for SPHERE scenes
+ *                    whose every arithmetic step is a call into the reference headers
+ *                    (get_ray, sphereHit, material_scatter, rnd, wang_hash, vec3 operators).
+ *                    The reference at HEAD has no sphere scene, so the
+ *                    loop's control flow is ours; it follows render()/color()/hit() of
+ *                    kernels.cu:325-360,396-569 with the sphere list in place of the mesh.
+ */
+#include <cstdint>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "rnd.h"
+#include "camera.h"
+#include "intersections.h"
+#include "material.h"
+#include "scene_materials.h"
+
+#define STB_IMAGE_IMPLEMENTATION
+#include "stb_image.h"
+#include <fstream>
+#include <sstream>
+#include "staircase_scene.h"
+
+#include "../include/rt_types.h"
+#include "rt_oracle.h"      /* orc_scatter / orc_counters struct shapes only */
+
+static_assert(sizeof(vec3) == sizeof(rt_vec3), "vec3");
+static_assert(sizeof(camera) == sizeof(rt_camera), "camera");
+static_assert(sizeof(sphere) == sizeof(rt_sphere), "sphere");
+static_assert(sizeof(plane) == sizeof(rt_plane), "plane");
+static_assert(sizeof(bbox) == sizeof(rt_bbox), "bbox");
+static_assert(sizeof(triangle) == sizeof(rt_triangle), "triangle");
+static_assert(sizeof(bvh_node) == sizeof(rt_bvh_node), "bvh_node");
+static_assert(sizeof(material) == sizeof(rt_material), "material");
+static_assert(sizeof(stexture) == sizeof(rt_stexture), "stexture");
+static_assert(sizeof(mesh) == sizeof(rt_mesh), "mesh");
+static_assert(sizeof(kernel_scene) == sizeof(rt_kernel_scene), "kernel_scene");
+static_assert(offsetof(camera, lens_radius) == offsetof(rt_camera, lens_radius), "camera.lens_radius");
+static_assert(offsetof(triangle, meshID) == offsetof(rt_triangle, meshID), "triangle.meshID");
+static_assert(offsetof(material, texId) == offsetof(rt_material, texId), "material.texId");
+static_assert(offsetof(mesh, bounds) == offsetof(rt_mesh, bounds), "mesh.bounds");
+static_assert(offsetof(kernel_scene, numPrimitivesPerLeaf) == offsetof(rt_kernel_scene, numPrimitivesPerLeaf), "ks.nppl");
+
+static inline vec3 V(const float* p) { return vec3(p[0], p[1], p[2]); }
+static inline void S(float* p, const vec3& v) { p[0] = v.x(); p[1] = v.y(); p[2] = v.z(); }
+
+extern "C" {
+
+int ref_struct_sizes(int* out, int cap) {
+    const int s[] = { (int)sizeof(vec3), (int)sizeof(ray), (int)sizeof(camera), (int)sizeof(sphere), (int)sizeof(plane),
+                      (int)sizeof(bbox), (int)sizeof(triangle), (int)sizeof(bvh_node), (int)sizeof(material),
+                      (int)sizeof(stexture), (int)sizeof(mesh), (int)sizeof(scene), (int)sizeof(kernel_scene),
+                      (int)sizeof(intersection), (int)sizeof(scatter_info), (int)sizeof(path), (int)sizeof(tri_hit) };
+    int n = (int)(sizeof(s) / sizeof(s[0]));
+    for (int i = 0; i < n && i < cap; i++) out[i] = s[i];
+    return n;
+}
+
+uint32_t ref_wang_hash(uint32_t seed) { return wang_hash(seed); }
+uint32_t ref_pixel_seed(uint32_t pixel_id) { return (wang_hash(pixel_id) * 336343633) | 1; }
+uint32_t ref_xor_shift_32(uint32_t* state) { return xor_shift_32(*state); }
+float    ref_rnd(uint32_t* state) { return rnd(*state); }
+void     ref_random_in_unit_disk(uint32_t* state, float out[3]) { S(out, random_in_unit_disk(*state)); }
+void     ref_random_in_unit_sphere(uint32_t* state, float out[3]) { S(out, random_in_unit_sphere(*state)); }
+
+void ref_make_camera(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,
+                     float aspect, float aperture, float focus_dist, rt_camera* out) {
+    /* route every input through volatile so the constructor runs at run time (SURVEY.md §8c finding 2) */
+    volatile float in[13];
+    for (int i = 0; i < 3; i++) { in[i] = lookfrom[i]; in[3 + i] = lookat[i]; in[6 + i] = vup[i]; }
+    in[9] = vfov; in[10] = aspect; in[11] = aperture; in[12] = focus_dist;
+    camera c(vec3(in[0], in[1], in[2]), vec3(in[3], in[4], in[5]), vec3(in[6], in[7], in[8]), in[9], in[10], in[11], in[12]);
+    memcpy(out, &c, sizeof c);
+}
+
+void ref_get_ray(const rt_camera* c, float s, float t, uint32_t* state, float org[3], float dir[3]) {
+    camera cam; memcpy(&cam, c, sizeof cam);
+    ray r = get_ray(cam, s, t, *state);
+    S(org, r.origin()); S(dir, r.direction());
+}
+
+float ref_sphere_hit(const rt_sphere* s, const float org[3], const float dir_in[3], float t_min, float t_max) {
+    sphere sp; memcpy(&sp, s, sizeof sp);
+    return sphereHit(sp, ray(V(org), V(dir_in)), t_min, t_max);
+}
+float ref_triangle_hit(const rt_triangle* tri, const float org[3], const float dir_in[3], float t_min, float t_max,
+                       float* hitU, float* hitV) {
+    triangle t; memcpy(&t, tri, sizeof t);
+    return triangleHit(t, ray(V(org), V(dir_in)), t_min, t_max, *hitU, *hitV);
+}
+int ref_hit_bbox(const float bmin[3], const float bmax[3], const float org[3], const float dir_in[3], float t_max) {
+    return hit_bbox(V(bmin), V(bmax), ray(V(org), V(dir_in)), t_max) ? 1 : 0;
+}
+float ref_hit_bbox_dist(const float bmin[3], const float bmax[3], const float org[3], const float dir_in[3], float t_max) {
+    return hit_bbox_dist(V(bmin), V(bmax), ray(V(org), V(dir_in)), t_max);
+}
+float ref_plane_hit(const rt_plane* p, const float org[3], const float dir_in[3], float t_min, float t_max) {
+    plane pl; memcpy(&pl, p, sizeof pl);
+    return planeHit(pl, ray(V(org), V(dir_in)), t_min, t_max);
+}
+
+float ref_schlick(float cosine, float ref_idx) { return schlick(cosine, ref_idx); }
+void  ref_reflect(const float v[3], const float n[3], float out[3]) { S(out, reflect(V(v), V(n))); }
+void  ref_refract(const float uv[3], const float n[3], float e, float out[3]) { S(out, refract(V(uv), V(n), e)); }
+
+void ref_material_scatter(float inters_t, const float normal[3], int inside, const float wo[3],
+                          const rt_material* mat, const float color[3], uint32_t* rng, orc_scatter* out) {
+    intersection in; memset((void*)&in, 0, sizeof in);
+    in.t = inters_t; in.normal = V(normal); in.inside = inside != 0;
+    material m; memcpy(&m, mat, sizeof m);
+    scatter_info sc(in);
+    material_scatter(sc, in, V(wo), m, V(color), *rng);
+    S(out->wi, sc.wi); out->specular = sc.specular; S(out->throughput, sc.throughput);
+    out->refracted = sc.refracted; out->t = sc.t;
+}
+
+uint32_t ref_linear_to_srgb(float x) { return LinearToSRGB(x); }
+
+/* Expression probes: the two vec3 expressions of generateShadowRay whose operator order matters
+ * (kernels.cu:379 and :387), evaluated with the reference's own vec3 operators. */
+void ref_probe_light_dir(const float su[3], const float sv[3], const float sw[3], float phi, float sinA, float cosA, float out[3]) {
+    const vec3 l = V(su) * cosf(phi) * sinA + V(sv) * sinf(phi) * sinA + V(sw) * cosA;
+    S(out, l);
+}
+void ref_probe_light_contribution(const float att[3], const float lightColor[3], float dotl, float cosAMax, float out[3]) {
+    const float omega = 2 * M_PI * (1.0f - cosAMax);
+    const vec3 c = V(att) * V(lightColor) * dotl * omega / M_PI;
+    S(out, c);
+}
+float ref_probe_phi(float eps2) { const float phi = 2 * M_PI * eps2; return phi; }
+
+/* Host loop for sphere scenes built from the reference's functions (see file header). */
+void ref_render_spheres(const rt_sphere* spheres_, const rt_material* mats_, int n, const rt_camera* cam_,
+                        int sky_gradient, int rr, float t_min, int counter_rng,
+                        int nx, int ny, int ns, int max_depth,
+                        int x0, int y0, int x1, int y1, rt_vec3* fb_, orc_counters* cnt) {
+    const sphere* spheres = reinterpret_cast<const sphere*>(spheres_);
+    const material* mats = reinterpret_cast<const material*>(mats_);
+    camera cam; memcpy(&cam, cam_, sizeof cam);
+    vec3* fb = reinterpret_cast<vec3*>(fb_);
+    if (max_depth > 255) max_depth = 255;
+
+    for (int j = y0; j < y1; j++)
+        for (int i = x0; i < x1; i++) {
+            path p;
+            uint64_t pixelId = j * nx + i;
+            p.rng = (wang_hash(pixelId) * 336343633) | 1;
+            vec3 col(0, 0, 0);
+            for (int s = 0; s < ns; s++) {
+                if (counter_rng) p.rng = (wang_hash((uint32_t)pixelId + wang_hash((uint32_t)s) * 0x9E3779B9u) * 336343633) | 1;
+                float u = float(i + rnd(p.rng)) / float(nx);
+                float v = float(j + rnd(p.rng)) / float(ny);
+                ray r0 = get_ray(cam, u, v, p.rng);
+                p.origin = r0.origin();
+                p.rayDir = r0.direction();
+                p.specular = false;
+                p.inside = false;
+                p.attenuation = vec3(1.0, 1.0, 1.0);
+                p.color = vec3(0, 0, 0);
+                for (p.bounce = 0; p.bounce < max_depth; p.bounce++) {
+                    const ray r(p.origin, p.rayDir);
+                    if (cnt) cnt->rays++;
+                    float closest = FLT_MAX;
+                    int sid = -1;
+                    for (int k = 0; k < n; k++) {
+                        float t = sphereHit(spheres[k], r, t_min, closest);
+                        if (t < closest) { closest = t; sid = k; }
+                    }
+                    if (cnt) cnt->prim_tests += n;
+                    if (sid < 0) {
+                        if (sky_gradient) {
+                            float t = 0.5f * (p.rayDir.y() + 1.0f);
+                            vec3 c = (1.0f - t) * vec3(1.0, 1.0, 1.0) + t * vec3(0.5, 0.7, 1.0);
+                            p.color += p.attenuation * c;
+                        } else {
+                            p.color += p.attenuation * vec3(0.5f, 0.5f, 0.5f);
+                        }
+                        break;
+                    }
+                    if (cnt) cnt->hits++;
+                    intersection inters;
+                    inters.t = closest;
+                    inters.p = r.point_at_parameter(inters.t);
+                    inters.normal = (inters.p - spheres[sid].center) / spheres[sid].radius;
+                    if (dot(r.direction(), inters.normal) > 0.0f)
+                        inters.normal = -inters.normal;
+                    inters.inside = p.inside;
+                    scatter_info scatter(inters);
+                    material_scatter(scatter, inters, p.rayDir, mats[sid], mats[sid].color, p.rng);
+                    p.origin += scatter.t * p.rayDir;
+                    p.rayDir = scatter.wi;
+                    p.attenuation *= scatter.throughput;
+                    p.specular = scatter.specular;
+                    p.inside = scatter.refracted ? !p.inside : p.inside;
+                    if (rr && p.bounce > 3) {
+                        float m = max(p.attenuation);
+                        if (rnd(p.rng) > m) break;
+                        p.attenuation *= 1 / m;
+                    }
+                }
+                col += p.color;
+                if (cnt) cnt->samples++;
+            }
+            fb[pixelId] = col / float(ns);
+        }
+}
+
+} /* extern "C" */

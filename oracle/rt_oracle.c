@@ -1,0 +1,643 @@
+/*
+ * rt_oracle.c — CPU ORACLE. TEST INFRASTRUCTURE ONLY (see rt_oracle.h).
+ *
+ * Plain C99, single-threaded.  Build: gcc -O2 -ffp-contract=off (never -ffast-math).
+ * Every function cites the reference lines it restates; citations are relative to
+ * /root/reference/.  All arithmetic is fp32 unless a reference expression is double
+ * (those are kept in double and narrowed at the same place the reference narrows).
+ */
+#define _GNU_SOURCE 1   /* M_PI under -std=c99 */
+#include "rt_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- vec3.h ------------------ */
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 ld(const float* p) { return V(p[0], p[1], p[2]); }
+static inline v3 ldv(rt_vec3 a) { return V(a.e[0], a.e[1], a.e[2]); }
+static inline void st(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }            /* vec3.h:59-61 */
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }            /* vec3.h:63-65 */
+static inline v3 mulv(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }           /* vec3.h:67-69 */
+static inline v3 muls(float t, v3 a) { return V(t * a.x, t * a.y, t * a.z); }              /* vec3.h:75-77,83-85 */
+static inline v3 divs(v3 a, float t) { return V(a.x / t, a.y / t, a.z / t); }              /* vec3.h:79-81 */
+static inline v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }                                 /* vec3.h:23 */
+static inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          /* vec3.h:87-89 */
+static inline v3 cross(v3 a, v3 b) {                                                       /* vec3.h:91-95 */
+    return V((a.y * b.z - a.z * b.y), (-(a.x * b.z - a.z * b.x)), (a.x * b.y - a.y * b.x));
+}
+static inline float sqlen(v3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }              /* vec3.h:36 */
+static inline float len(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }         /* vec3.h:35 */
+static inline v3 unit(v3 a) { return divs(a, len(a)); }                                    /* vec3.h:194-196 */
+static inline float max3(v3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }                     /* vec3.h:113-115 */
+
+/* ---------------------------------------------------------------- rnd.h ------------------- */
+
+uint32_t orc_xor_shift_32(uint32_t* state) {    /* rnd.h:5-13 */
+    uint32_t x = *state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 15;
+    *state = x;
+    return x;
+}
+
+float orc_rnd(uint32_t* state) {                /* rnd.h:15-18 */
+    return (float)(orc_xor_shift_32(state) & 0xFFFFFF) / 16777216.0f;
+}
+
+uint32_t orc_wang_hash(uint32_t seed) {         /* rnd.h:31-39 */
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+
+uint32_t orc_pixel_seed(uint32_t pixel_id) {    /* kernels.cu:541-542 */
+    return (orc_wang_hash(pixel_id) * 336343633u) | 1u;
+}
+
+/* RT_RNG_COUNTER (additive, not in the reference): one xorshift32 stream per (pixel, sample)
+ * instead of per pixel, so samples are independent work items. */
+static uint32_t sample_seed(uint32_t pixel_id, uint32_t s) {
+    return (orc_wang_hash(pixel_id + orc_wang_hash(s) * 0x9E3779B9u) * 336343633u) | 1u;
+}
+
+static uint64_t* g_draws = 0;
+static inline float rnd(uint32_t* st_) { if (g_draws) (*g_draws)++; return orc_rnd(st_); }
+
+static v3 random_in_unit_disk(uint32_t* state) {    /* rnd.h:20-26; draws pinned x then y */
+    v3 p;
+    do {
+        float rx = rnd(state);
+        float ry = rnd(state);
+        p = sub(muls(2.0f, V(rx, ry, 0.0f)), V(1.0f, 1.0f, 0.0f));
+    } while (dot(p, p) >= 1.0f);
+    return p;
+}
+
+static v3 random_in_unit_sphere(uint32_t* state) {  /* rnd.h:41-49; draws pinned x,y,z */
+    v3 p;
+    do {
+        float rx = rnd(state);
+        float ry = rnd(state);
+        float rz = rnd(state);
+        p = sub(muls(2.0f, V(rx, ry, rz)), V(1.0f, 1.0f, 1.0f));
+    } while (sqlen(p) >= 1.0f);
+    return p;
+}
+
+void orc_random_in_unit_disk(uint32_t* state, float out[3]) { st(out, random_in_unit_disk(state)); }
+void orc_random_in_unit_sphere(uint32_t* state, float out[3]) { st(out, random_in_unit_sphere(state)); }
+
+/* ---------------------------------------------------------------- ray.h / camera ---------- */
+
+typedef struct { v3 A, B; } ray_t;
+static inline ray_t mkray(v3 a, v3 b) { ray_t r; r.A = a; r.B = unit(b); return r; }       /* ray.h:9 */
+static inline v3 point_at(const ray_t* r, float t) { return add(r->A, muls(t, r->B)); }     /* ray.h:12 */
+
+void orc_make_camera(const float lookfrom_[3], const float lookat_[3], const float vup_[3], float vfov,
+                     float aspect, float aperture, float focus_dist, rt_camera* out) {
+    /* helper_structs.h:194-207 */
+    v3 lookfrom = ld(lookfrom_), lookat = ld(lookat_), vup = ld(vup_);
+    float lens_radius = aperture / 2.0f;
+    float theta = vfov * ((float)M_PI) / 180.0f;
+    float half_height = tanf(theta / 2.0f);
+    float half_width = aspect * half_height;
+    v3 origin = lookfrom;
+    v3 w = unit(sub(lookfrom, lookat));
+    v3 u = unit(cross(vup, w));
+    v3 v = cross(w, u);
+    /* origin - half_width*focus_dist*u - half_height*focus_dist*v - focus_dist*w  (left to right) */
+    v3 llc = sub(sub(sub(origin, muls(half_width * focus_dist, u)), muls(half_height * focus_dist, v)), muls(focus_dist, w));
+    v3 horizontal = muls(2.0f * half_width * focus_dist, u);
+    v3 vertical = muls(2.0f * half_height * focus_dist, v);
+    st(out->origin.e, origin);
+    st(out->lower_left_corner.e, llc);
+    st(out->horizontal.e, horizontal);
+    st(out->vertical.e, vertical);
+    st(out->u.e, u); st(out->v.e, v); st(out->w.e, w);
+    out->lens_radius = lens_radius;
+}
+
+static ray_t get_ray(const rt_camera* c, float s, float t, uint32_t* state) {   /* camera.h:8-12 */
+    v3 rd = muls(c->lens_radius, random_in_unit_disk(state));
+    v3 offset = add(muls(rd.x, ldv(c->u)), muls(rd.y, ldv(c->v)));
+    v3 o = add(ldv(c->origin), offset);
+    v3 d = sub(sub(add(add(ldv(c->lower_left_corner), muls(s, ldv(c->horizontal))), muls(t, ldv(c->vertical))),
+                   ldv(c->origin)), offset);
+    return mkray(o, d);
+}
+
+void orc_get_ray(const rt_camera* c, float s, float t, uint32_t* state, float org[3], float dir[3]) {
+    ray_t r = get_ray(c, s, t, state);
+    st(org, r.A); st(dir, r.B);
+}
+
+/* ---------------------------------------------------------------- intersections.h --------- */
+
+static inline float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+static int hit_bbox(v3 bmin, v3 bmax, const ray_t* r, float t_max) {            /* intersections.h:7-23 */
+    float t_min = 0.001f;
+    for (int a = 0; a < 3; a++) {
+        float invD = 1.0f / comp(r->B, a);
+        float t0 = (comp(bmin, a) - comp(r->A, a)) * invD;
+        float t1 = (comp(bmax, a) - comp(r->A, a)) * invD;
+        if (invD < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max < t_min) return 0;
+    }
+    return 1;
+}
+
+static float hit_bbox_dist(v3 bmin, v3 bmax, const ray_t* r, float t_max) {     /* intersections.h:25-41 */
+    float t_min = 0.001f;
+    for (int a = 0; a < 3; a++) {
+        float invD = 1.0f / comp(r->B, a);
+        float t0 = (comp(bmin, a) - comp(r->A, a)) * invD;
+        float t1 = (comp(bmax, a) - comp(r->A, a)) * invD;
+        if (invD < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max < t_min) return FLT_MAX;
+    }
+    return t_min;
+}
+
+static float plane_hit(const rt_plane* p, const ray_t* r, float t_min, float t_max) {   /* intersections.h:43-52 */
+    float denom = dot(ldv(p->norm), r->B);
+    if (denom > -0.000001f) return FLT_MAX;
+    v3 po = sub(ldv(p->point), r->A);
+    float t = dot(po, ldv(p->norm)) / denom;
+    if (t < t_min || t > t_max) return FLT_MAX;
+    return t;
+}
+
+static float triangle_hit(const rt_triangle* tri, const ray_t* r, float t_min, float t_max, float* hitU, float* hitV) {
+    /* intersections.h:54-83 */
+    const float EPS = 0.0000001;                 /* double literal narrowed to float, :55 */
+    v3 v0 = ldv(tri->v[0]);
+    v3 edge1 = sub(ldv(tri->v[1]), v0);
+    v3 edge2 = sub(ldv(tri->v[2]), v0);
+    v3 h = cross(r->B, edge2);
+    float a = dot(edge1, h);
+    if (a > -EPS && a < EPS) return FLT_MAX;
+    float f = (float)(1.0 / (double)a);          /* :64 double divide, narrowed */
+    v3 s = sub(r->A, v0);
+    float u = f * dot(s, h);
+    if ((double)u < 0.0 || (double)u > 1.0) return FLT_MAX;
+    v3 q = cross(s, edge1);
+    float v = f * dot(r->B, q);
+    if ((double)v < 0.0 || (double)(u + v) > 1.0) return FLT_MAX;
+    float t = f * dot(edge2, q);
+    if (t > t_min && t < t_max) { *hitU = u; *hitV = v; return t; }
+    return FLT_MAX;
+}
+
+static float sphere_hit(const rt_sphere* s, const ray_t* r, float t_min, float t_max) {  /* intersections.h:85-104 */
+    v3 oc = sub(r->A, ldv(s->center));
+    float a = dot(r->B, r->B);
+    float b = dot(oc, r->B);
+    float c = dot(oc, oc) - s->radius * s->radius;
+    float discriminant = b * b - a * c;
+    if (discriminant > 0) {
+        float temp = (-b - sqrtf(discriminant)) / a;
+        if (temp < t_max && temp > t_min) return temp;
+        temp = (-b + sqrtf(discriminant)) / a;
+        if (temp < t_max && temp > t_min) return temp;
+    }
+    return FLT_MAX;
+}
+
+float orc_sphere_hit(const rt_sphere* s, const float org[3], const float dir_in[3], float t_min, float t_max) {
+    ray_t r = mkray(ld(org), ld(dir_in));
+    return sphere_hit(s, &r, t_min, t_max);
+}
+float orc_triangle_hit(const rt_triangle* tri, const float org[3], const float dir_in[3], float t_min, float t_max,
+                       float* hitU, float* hitV) {
+    ray_t r = mkray(ld(org), ld(dir_in));
+    return triangle_hit(tri, &r, t_min, t_max, hitU, hitV);
+}
+int orc_hit_bbox(const float bmin[3], const float bmax[3], const float org[3], const float dir_in[3], float t_max) {
+    ray_t r = mkray(ld(org), ld(dir_in));
+    return hit_bbox(ld(bmin), ld(bmax), &r, t_max);
+}
+float orc_hit_bbox_dist(const float bmin[3], const float bmax[3], const float org[3], const float dir_in[3], float t_max) {
+    ray_t r = mkray(ld(org), ld(dir_in));
+    return hit_bbox_dist(ld(bmin), ld(bmax), &r, t_max);
+}
+float orc_plane_hit(const rt_plane* p, const float org[3], const float dir_in[3], float t_min, float t_max) {
+    ray_t r = mkray(ld(org), ld(dir_in));
+    return plane_hit(p, &r, t_min, t_max);
+}
+
+/* ---------------------------------------------------------------- material.h -------------- */
+
+typedef struct {            /* intersection, helper_structs.h:16-36 (the members the path uses) */
+    uint32_t objId;
+    unsigned char meshID;
+    float t;
+    v3 p;
+    v3 normal;
+    int inside;
+    float texCoords[2];
+} inters_t;
+
+typedef struct { v3 wi; int specular; v3 throughput; int refracted; float t; } scat_t;   /* helper_structs.h:38-46 */
+
+float orc_schlick(float cosine, float ref_idx) {        /* material.h:9-13 */
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powf((1.0f - cosine), 5.0f);
+}
+
+static v3 refract_(v3 uv, v3 n, float etai_over_etat) { /* material.h:15-21 */
+    float cos_theta = fminf(dot(neg(uv), n), 1.0f);
+    v3 r_out_parallel = muls(etai_over_etat, add(uv, muls(cos_theta, n)));
+    float sl = sqlen(r_out_parallel);
+    v3 r_out_perp = sl >= 1.0f ? V(0, 0, 0) : muls(-sqrtf(1.0f - sl), n);
+    return add(r_out_parallel, r_out_perp);
+}
+
+static v3 reflect_(v3 v, v3 n) {                        /* material.h:23-25 */
+    return sub(v, muls(2.0f * dot(v, n), n));
+}
+
+void orc_reflect(const float v[3], const float n[3], float out[3]) { st(out, reflect_(ld(v), ld(n))); }
+void orc_refract(const float uv[3], const float n[3], float e, float out[3]) { st(out, refract_(ld(uv), ld(n), e)); }
+
+static void diffuse_bsdf(scat_t* out, const inters_t* i, v3 albedo, uint32_t* rng) {    /* material.h:27-31 */
+    out->wi = unit(add(i->normal, random_in_unit_sphere(rng)));
+    out->throughput = albedo;
+    out->specular = 0;
+}
+
+static void glossy_bsdf(scat_t* out, const inters_t* i, v3 wo, v3 tint, float fuzz, uint32_t* rng) { /* material.h:46-53 */
+    v3 reflected = reflect_(wo, i->normal);
+    if (fuzz > 0.0001f)
+        reflected = add(reflected, muls(fuzz, random_in_unit_sphere(rng)));
+    out->wi = unit(reflected);
+    out->throughput = mulv(out->throughput, tint);
+    out->specular = 1;
+}
+
+static int fresnel_layer(const inters_t* i, v3 wo, float ior, uint32_t* rng) {           /* material.h:55-60 */
+    float etai_over_etat = i->inside ? ior : (1.0f / ior);
+    float cos_theta = fminf(dot(neg(wo), i->normal), 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    return (etai_over_etat * sin_theta > 1.0f || rnd(rng) < orc_schlick(cos_theta, etai_over_etat));
+}
+
+static void dielectric_bsdf(scat_t* out, const inters_t* i, v3 wo, float layer_ior, v3 glossy_tint, float glossy_fuzz,
+                            v3 absorption, uint32_t* rng) {                              /* material.h:73-92 */
+    if (i->inside) {
+        v3 e = muls(i->t, neg(absorption));          /* -absorptionCoefficient * i.t */
+        out->throughput = V(expf(e.x), expf(e.y), expf(e.z));
+    }
+    if (fresnel_layer(i, wo, layer_ior, rng)) {
+        glossy_bsdf(out, i, wo, glossy_tint, glossy_fuzz, rng);
+    } else {
+        float etai_over_etat = i->inside ? layer_ior : (1.0f / layer_ior);
+        out->wi = unit(refract_(wo, i->normal, etai_over_etat));
+        out->refracted = 1;
+    }
+    out->specular = 1;
+}
+
+static void material_scatter(scat_t* out, const inters_t* i, v3 wo, const rt_material* mat, v3 color, uint32_t* rng) {
+    /* scene_materials.h:13-20 */
+    if (mat->type == RT_DIFFUSE)
+        diffuse_bsdf(out, i, color, rng);
+    else if (mat->type == RT_METAL)
+        glossy_bsdf(out, i, wo, color, mat->param, rng);
+    else
+        dielectric_bsdf(out, i, wo, mat->param, color, 0.0f, V(0, 0, 0), rng);
+}
+
+static inline scat_t scat_init(const inters_t* i) {     /* helper_structs.h:45 */
+    scat_t s;
+    s.wi = V(0, 0, 0);
+    s.specular = 0; s.throughput = V(1, 1, 1); s.refracted = 0; s.t = i->t;
+    return s;
+}
+
+void orc_material_scatter(float inters_t_, const float normal[3], int inside, const float wo[3],
+                          const rt_material* mat, const float color[3], uint32_t* rng, orc_scatter* out) {
+    inters_t i; memset(&i, 0, sizeof i);
+    i.t = inters_t_; i.normal = ld(normal); i.inside = inside;
+    scat_t s = scat_init(&i);
+    material_scatter(&s, &i, ld(wo), mat, ld(color), rng);
+    st(out->wi, s.wi); out->specular = s.specular; st(out->throughput, s.throughput);
+    out->refracted = s.refracted; out->t = s.t;
+}
+
+/* ---------------------------------------------------------------- kernels.cu -------------- */
+
+enum { OBJ_NONE = 0, OBJ_TRIMESH = 1, OBJ_PLANE = 2, OBJ_LIGHT = 3, OBJ_SPHERE = 4 };   /* kernels.cu:40-45 (+SPHERE) */
+
+typedef struct {            /* path, helper_structs.h:48-71 */
+    v3 origin, rayDir, color;
+    int specular;
+    v3 shadowDir, lightContribution;
+    int bounce;
+    v3 attenuation;
+    uint32_t rng;
+    int inside;
+} path_t;
+
+typedef struct {
+    const orc_scene* sc;
+    const rt_render_options* opt;
+    orc_counters* cnt;
+    int max_depth;
+} ctx_t;
+
+static inline void pop_bitstack(uint32_t* bitStack, int* idx) {     /* kernels.cu:148-152 */
+    int m = __builtin_ffsll((long long)*bitStack) - 1;
+    *bitStack = (*bitStack >> m) ^ 1u;
+    *idx = (*idx >> m) ^ 1;
+}
+
+static float hit_bvh(const orc_scene* sc, const ray_t* r, float t_min, float t_max, int is_shadow,
+                     uint32_t* triId, float* hu, float* hv, orc_counters* cnt) {         /* kernels.cu:154-224 */
+    int idx = 1;
+    float closest = t_max;
+    uint32_t bitStack = 1;
+    const uint32_t firstLeafIdx = (uint32_t)(sc->num_bvh_nodes / 2);                     /* kernels.cu:614 */
+    while (idx) {
+        if ((uint32_t)idx < firstLeafIdx) {
+            int idx2 = idx << 1;
+            const rt_bvh_node* L = &sc->bvh[idx2];
+            const rt_bvh_node* R = &sc->bvh[idx2 + 1];
+            if (cnt) cnt->node_visits++;
+            float leftHit = hit_bbox_dist(ldv(L->a), ldv(L->b), r, closest);
+            int traverseLeft = leftHit < closest;
+            float rightHit = hit_bbox_dist(ldv(R->a), ldv(R->b), r, closest);
+            int traverseRight = rightHit < closest;
+            int swap = rightHit < leftHit;
+            if (traverseLeft && traverseRight) {
+                idx = idx2 + (swap ? 1 : 0);
+                bitStack = (bitStack << 1) + 1;
+            } else if (traverseLeft || traverseRight) {
+                idx = idx2 + (swap ? 1 : 0);
+                bitStack = bitStack << 1;
+            } else {
+                pop_bitstack(&bitStack, &idx);
+            }
+        } else {
+            int first = (int)((uint32_t)idx - firstLeafIdx) * sc->nppl;
+            for (int i = 0; i < sc->nppl; i++) {
+                const rt_triangle* tri = &sc->tris[first + i];
+                if (isinf(tri->v[0].e[0])) break;
+                float u, v;
+                if (cnt) cnt->prim_tests++;
+                float hitT = triangle_hit(tri, r, t_min, closest, &u, &v);
+                if (hitT < closest) {
+                    if (is_shadow) return 0.0f;
+                    closest = hitT;
+                    *triId = (uint32_t)(first + i);
+                    *hu = u; *hv = v;
+                }
+            }
+            pop_bitstack(&bitStack, &idx);
+        }
+    }
+    return closest;
+}
+
+float orc_hit_bvh(const orc_scene* sc, const float org[3], const float dir_in[3], float t_min, float t_max,
+                  int is_shadow, uint32_t* tri_id, float* u, float* v, orc_counters* cnt) {
+    ray_t r = mkray(ld(org), ld(dir_in));
+    return hit_bvh(sc, &r, t_min, t_max, is_shadow, tri_id, u, v, cnt);
+}
+
+static float hit_mesh(const ctx_t* c, const ray_t* r, float t_min, float t_max, int is_shadow,
+                      uint32_t* triId, float* hu, float* hv) {                           /* kernels.cu:296-323 */
+    if (!hit_bbox(ldv(c->sc->bounds.min), ldv(c->sc->bounds.max), r, t_max)) return FLT_MAX;
+    return hit_bvh(c->sc, r, t_min, t_max, is_shadow, triId, hu, hv, c->cnt);
+}
+
+/* Sphere-scene closest hit: the linear scan the README-era renderer did over its sphere list,
+ * each test being sphereHit (intersections.h:85-104) against the running closest t.  For
+ * shadow rays any hit ends the scan (same any-hit rule as hitBvh, kernels.cu:205). */
+static float hit_spheres(const ctx_t* c, const ray_t* r, float t_min, float t_max, int is_shadow, int* sid) {
+    float closest = t_max;
+    for (int k = 0; k < c->sc->num_spheres; k++) {
+        if (c->cnt) c->cnt->prim_tests++;
+        float t = sphere_hit(&c->sc->spheres[k], r, t_min, closest);
+        if (t < closest) {
+            if (is_shadow) return 0.0f;
+            closest = t;
+            *sid = k;
+        }
+    }
+    return closest;
+}
+
+/* hit(), kernels.cu:325-360.  Mesh scenes follow it line by line.  Sphere scenes replace the
+ * hitMesh call by hit_spheres and the triangle normal by (p - center) / radius
+ * (intersections.h:95, the commented rec.normal); everything else is shared. */
+static int hit(const ctx_t* c, const path_t* p, float t_max, int is_shadow, inters_t* in, int* sid) {
+    const ray_t r = is_shadow ? mkray(p->origin, p->shadowDir) : mkray(p->origin, p->rayDir);
+    const float eps = c->opt->t_min;
+    in->objId = OBJ_NONE;
+    if (c->sc->num_spheres > 0) {
+        int k = -1;
+        if ((in->t = hit_spheres(c, &r, eps, t_max, is_shadow, &k)) < t_max) {
+            if (is_shadow) return 1;
+            in->objId = OBJ_SPHERE;
+            *sid = k;
+            in->p = point_at(&r, in->t);
+            in->normal = divs(sub(in->p, ldv(c->sc->spheres[k].center)), c->sc->spheres[k].radius);
+        } else {
+            if (is_shadow) return 0;
+        }
+    } else {
+        uint32_t triId = 0; float hu = 0, hv = 0;
+        if ((in->t = hit_mesh(c, &r, eps, t_max, is_shadow, &triId, &hu, &hv)) < t_max) {
+            if (is_shadow) return 1;
+            in->objId = OBJ_TRIMESH;
+            const rt_triangle* tri = &c->sc->tris[triId];
+            in->meshID = tri->meshID;
+            in->normal = unit(cross(sub(ldv(tri->v[1]), ldv(tri->v[0])), sub(ldv(tri->v[2]), ldv(tri->v[0]))));
+            in->texCoords[0] = (hu * tri->texCoords[1 * 2 + 0] + hv * tri->texCoords[2 * 2 + 0] + (1 - hu - hv) * tri->texCoords[0 * 2 + 0]);
+            in->texCoords[1] = (hu * tri->texCoords[1 * 2 + 1] + hv * tri->texCoords[2 * 2 + 1] + (1 - hu - hv) * tri->texCoords[0 * 2 + 1]);
+        } else {
+            if (is_shadow) return 0;
+            if (p->specular && sphere_hit(&c->opt->light, &r, eps, t_max) < t_max) {   /* kernels.cu:346 */
+                in->objId = OBJ_LIGHT;
+                return 1;
+            }
+        }
+    }
+    if (in->objId != OBJ_NONE) {
+        if (in->objId == OBJ_TRIMESH) in->p = point_at(&r, in->t);
+        if (dot(r.B, in->normal) > 0.0f) in->normal = neg(in->normal);
+        return 1;
+    }
+    return 0;
+}
+
+static int generate_shadow_ray(const ctx_t* c, path_t* p, const inters_t* in, float* lightDist) {  /* kernels.cu:363-393 */
+    const rt_sphere* light = &c->opt->light;
+    const v3 lc = ldv(light->center);
+    const v3 sw = unit(sub(lc, p->origin));
+    const v3 su = unit(cross(fabsf(sw.x) > 0.01f ? V(0, 1, 0) : V(1, 0, 0), sw));
+    const v3 sv = cross(sw, su);
+
+    const float cosAMax = sqrtf(1.0f - light->radius * light->radius / sqlen(sub(p->origin, lc)));
+    if (isnan(cosAMax)) return 0;
+
+    const float eps1 = rnd(&p->rng);
+    const float eps2 = rnd(&p->rng);
+    const float cosA = 1.0f - eps1 + eps1 * cosAMax;
+    const float sinA = sqrtf(1.0f - cosA * cosA);
+    const float phi = (float)(2 * M_PI * (double)eps2);                  /* :378 double product, narrowed */
+    const v3 l = add(add(muls(sinA, muls(cosf(phi), su)), muls(sinA, muls(sinf(phi), sv))), muls(cosA, sw));
+
+    const float dotl = dot(l, in->normal);
+    if (dotl <= 0) return 0;
+
+    p->shadowDir = unit(l);
+    const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));    /* :386 */
+    p->lightContribution = divs(muls(omega, muls(dotl, mulv(p->attenuation, ldv(c->opt->lightColor)))), (float)M_PI); /* :387 */
+    *lightDist = len(sub(lc, p->origin)) - light->radius;
+    return 1;
+}
+
+static void color(const ctx_t* c, path_t* p) {                                          /* kernels.cu:396-533 */
+    p->attenuation = V(1.0f, 1.0f, 1.0f);
+    p->color = V(0, 0, 0);
+    const int maxDepth = c->max_depth > 255 ? 255 : c->max_depth;       /* uint8_t bounce, helper_structs.h:58 */
+    for (p->bounce = 0; p->bounce < maxDepth; p->bounce++) {
+        inters_t in; memset(&in, 0, sizeof in);
+        int sid = -1;
+        if (c->cnt) c->cnt->rays++;
+        if (!hit(c, p, FLT_MAX, 0, &in, &sid)) {
+            if (c->opt->sky == RT_SKY_GRADIENT) {                       /* kernels.cu:419-421 */
+                float t = 0.5f * (p->rayDir.y + 1.0f);
+                v3 sky = add(muls((1.0f - t), V(1.0f, 1.0f, 1.0f)), muls(t, V(0.5f, 0.7f, 1.0f)));
+                p->color = add(p->color, mulv(p->attenuation, sky));
+            } else {                                                    /* kernels.cu:424 */
+                p->color = add(p->color, mulv(p->attenuation, V(0.5f, 0.5f, 0.5f)));
+            }
+            return;
+        }
+        if (c->cnt) c->cnt->hits++;
+        if (in.objId == OBJ_LIGHT) {                                    /* kernels.cu:433-447 */
+            if (!c->opt->nee)                                           /* #ifndef SHADOW branch, :444-445 */
+                p->color = add(p->color, mulv(p->attenuation, ldv(c->opt->lightColor)));
+            return;
+        }
+
+        in.inside = p->inside;
+        scat_t sc = scat_init(&in);
+        if (in.objId == OBJ_SPHERE) {
+            const rt_material* mat = &c->sc->sphere_materials[sid];
+            material_scatter(&sc, &in, p->rayDir, mat, ldv(mat->color), &p->rng);
+        } else {                                                        /* kernels.cu:452-480 */
+            const rt_material* mat = &c->sc->materials[in.meshID];
+            v3 albedo;
+            if (mat->texId != -1) {
+                int texId = mat->texId;
+                int width = c->sc->textures[texId].width;
+                int height = c->sc->textures[texId].height;
+                float tu = in.texCoords[0];
+                tu = tu - floorf(tu);
+                float tv = in.texCoords[1];
+                tv = tv - floorf(tv);
+                const int tx = (int)((float)(width - 1) * tu);
+                const int ty = (int)((float)(height - 1) * tv);
+                const int tIdx = ty * width + tx;
+                const float* d = c->sc->textures[texId].data;
+                albedo = V(d[tIdx * 3 + 0], d[tIdx * 3 + 1], d[tIdx * 3 + 2]);
+            } else {
+                albedo = ldv(mat->color);
+            }
+            material_scatter(&sc, &in, p->rayDir, mat, albedo, &p->rng);
+        }
+
+        p->origin = add(p->origin, muls(sc.t, p->rayDir));             /* kernels.cu:485-489 */
+        p->rayDir = sc.wi;
+        p->attenuation = mulv(p->attenuation, sc.throughput);
+        p->specular = sc.specular;
+        p->inside = sc.refracted ? !p->inside : p->inside;
+
+        if (c->opt->nee) {                                              /* kernels.cu:490-511 */
+            float lightDist;
+            if (!p->specular && generate_shadow_ray(c, p, &in, &lightDist)) {
+                inters_t sh; memset(&sh, 0, sizeof sh);
+                int s2 = -1;
+                if (c->cnt) c->cnt->shadow_rays++;
+                if (!hit(c, p, lightDist, 1, &sh, &s2))
+                    p->color = add(p->color, p->lightContribution);
+            }
+        }
+        if (c->opt->rr) {                                               /* kernels.cu:512-527 */
+            if (p->bounce > 3) {
+                float m = max3(p->attenuation);
+                if (rnd(&p->rng) > m) return;
+                float k = 1 / m;
+                p->attenuation = V(p->attenuation.x * k, p->attenuation.y * k, p->attenuation.z * k); /* vec3.h:177-182 */
+            }
+        }
+    }
+}
+
+void orc_render(const orc_scene* scn, const rt_camera* cam, const rt_render_options* opt,
+                int nx, int ny, int ns, int max_depth,
+                int x0, int y0, int x1, int y1, rt_vec3* fb, orc_counters* counters) {  /* kernels.cu:535-569 */
+    ctx_t c; c.sc = scn; c.opt = opt; c.cnt = counters; c.max_depth = max_depth;
+    g_draws = counters ? &counters->rng_draws : 0;
+    for (int j = y0; j < y1; j++) {
+        for (int i = x0; i < x1; i++) {
+            path_t p; memset(&p, 0, sizeof p);
+            uint32_t pixelId = (uint32_t)(j * nx + i);
+            p.rng = orc_pixel_seed(pixelId);
+            v3 col = V(0, 0, 0);
+            for (int s = 0; s < ns; s++) {
+                if (opt->rng == RT_RNG_COUNTER) p.rng = sample_seed(pixelId, (uint32_t)s);
+                float u = ((float)i + rnd(&p.rng)) / (float)nx;
+                float v = ((float)j + rnd(&p.rng)) / (float)ny;
+                ray_t r = get_ray(cam, u, v, &p.rng);
+                p.origin = r.A;
+                p.rayDir = r.B;
+                p.specular = 0;
+                p.inside = 0;
+                color(&c, &p);
+                col = add(col, p.color);
+                if (counters) counters->samples++;
+            }
+            st(fb[pixelId].e, divs(col, (float)ns));
+        }
+    }
+    g_draws = 0;
+}
+
+/* ---------------------------------------------------------------- harness pieces ---------- */
+
+uint32_t orc_linear_to_srgb(float x) {          /* staircase_scene.h:22-30 */
+    x = fmaxf(x, 0.0f);
+    x = fmaxf(1.055f * powf(x, 0.416666667f) - 0.055f, 0.0f);
+    uint32_t u = (uint32_t)(x * 255.9f);
+    u = u < 255u ? u : 255u;
+    return u;
+}
+
+double orc_rmse(const rt_vec3* f, const rt_vec3* g, int n) {    /* main.cpp:117-125 */
+    double error = 0.0;
+    for (int i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++)
+            error += (f[i].e[c] - g[i].e[c]) * (f[i].e[c] - g[i].e[c]) / 3.0;
+    return sqrt(error / n);
+}
