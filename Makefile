@@ -29,10 +29,14 @@ $(OBJ)/mesh_parity.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
 $(OBJ)/mesh_fast.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -c $< -o $@
+$(OBJ)/probe_parity.o: $(CSRC)/rt_probe.hip $(KERNEL_HDRS) include/rt_probe.h | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
+$(OBJ)/probe_fast.o: $(CSRC)/rt_probe.hip $(KERNEL_HDRS) include/rt_probe.h | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -c $< -o $@
 $(OBJ)/renderer.o: $(CSRC)/rt_renderer.hip $(CSRC)/rt_params.h include/rt_api.h include/rt_types.h | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-RT_OBJS := $(OBJ)/renderer.o $(OBJ)/spheres_parity.o $(OBJ)/spheres_fast.o $(OBJ)/mesh_parity.o $(OBJ)/mesh_fast.o
+RT_OBJS := $(OBJ)/renderer.o $(OBJ)/probe_parity.o $(OBJ)/probe_fast.o $(OBJ)/spheres_parity.o $(OBJ)/spheres_fast.o $(OBJ)/mesh_parity.o $(OBJ)/mesh_fast.o
 
 $(PKG)/librt_mi355x.so: $(RT_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(RT_OBJS) -o $@

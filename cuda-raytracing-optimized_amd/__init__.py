@@ -414,3 +414,91 @@ def rmse(f, g):
     g = np.ascontiguousarray(g, dtype=np.float32)
     assert f.shape == g.shape
     return load_host().rtRmse(f.ctypes.data, g.ctypes.data, f.shape[1], f.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# per-function device probes (include/rt_probe.h)
+# ---------------------------------------------------------------------------------------------
+
+PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math")
+                 for m in ("parity", "fast")]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Probe:
+    """probe = Probe('parity'); probe.sphere_hit(...)  — every method returns numpy arrays."""
+
+    def __init__(self, mode="parity"):
+        assert mode in ("parity", "fast")
+        self.lib = load_renderer()
+        self.sfx = "_" + mode
+
+    def _fn(self, name):
+        f = getattr(self.lib, "rtProbe" + name + self.sfx)
+        f.restype = None
+        return f
+
+    def rng(self, pixel_ids):
+        ids = _u32(pixel_ids); n = len(ids)
+        seed = np.zeros(n, np.uint32); draws = np.zeros((n, 4), np.float32); state = np.zeros(n, np.uint32)
+        self._fn("Rng")(_p(ids), C.c_int(n), _p(seed), _p(draws), _p(state))
+        return seed, draws, state
+
+    def disk_sphere(self, states):
+        st = _u32(states); n = len(st)
+        disk = np.zeros((n, 3), np.float32); sd = np.zeros(n, np.uint32)
+        sph = np.zeros((n, 3), np.float32); ss = np.zeros(n, np.uint32)
+        self._fn("DiskSphere")(_p(st), C.c_int(n), _p(disk), _p(sd), _p(sph), _p(ss))
+        return disk, sd, sph, ss
+
+    def get_ray(self, cam, s, t, states):
+        s = _f32(s); t = _f32(t); st = _u32(states); n = len(s)
+        org = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32); sa = np.zeros(n, np.uint32)
+        self._fn("GetRay")(C.byref(cam), _p(s), _p(t), _p(st), C.c_int(n), _p(org), _p(d), _p(sa))
+        return org, d, sa
+
+    def sphere_hit(self, spheres, org, dirs, tmin, tmax):
+        sp = np.ascontiguousarray(spheres, dtype=sphere_dtype); n = len(sp)
+        org = _f32(org); dirs = _f32(dirs); tmin = _f32(tmin); tmax = _f32(tmax)
+        out = np.zeros(n, np.float32)
+        self._fn("SphereHit")(_p(sp), _p(org), _p(dirs), _p(tmin), _p(tmax), C.c_int(n), _p(out))
+        return out
+
+    def triangle_hit(self, tris, org, dirs, tmin, tmax):
+        tr = np.ascontiguousarray(tris, dtype=triangle_dtype); n = len(tr)
+        org = _f32(org); dirs = _f32(dirs); tmin = _f32(tmin); tmax = _f32(tmax)
+        t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        self._fn("TriangleHit")(_p(tr), _p(org), _p(dirs), _p(tmin), _p(tmax), C.c_int(n), _p(t), _p(u), _p(v))
+        return t, u, v
+
+    def bbox(self, bmin, bmax, org, dirs, tmax):
+        bmin = _f32(bmin); bmax = _f32(bmax); org = _f32(org); dirs = _f32(dirs); tmax = _f32(tmax); n = len(tmax)
+        dist = np.zeros(n, np.float32); hit = np.zeros(n, np.int32)
+        self._fn("Bbox")(_p(bmin), _p(bmax), _p(org), _p(dirs), _p(tmax), C.c_int(n), _p(dist), _p(hit))
+        return dist, hit
+
+    def scatter(self, t, normal, inside, wo, mats, color, states):
+        t = _f32(t); normal = _f32(normal); inside = np.ascontiguousarray(inside, dtype=np.int32); wo = _f32(wo)
+        mats = np.ascontiguousarray(mats, dtype=material_dtype); color = _f32(color); st = _u32(states); n = len(t)
+        wi = np.zeros((n, 3), np.float32); thr = np.zeros((n, 3), np.float32); flags = np.zeros(n, np.int32)
+        tout = np.zeros(n, np.float32); sa = np.zeros(n, np.uint32)
+        self._fn("Scatter")(_p(t), _p(normal), _p(inside), _p(wo), _p(mats), _p(color), _p(st), C.c_int(n),
+                            _p(wi), _p(thr), _p(flags), _p(tout), _p(sa))
+        return wi, thr, flags, tout, sa
+
+    def math(self, a, b):
+        a = _f32(a); b = _f32(b); n = len(a)
+        q = np.zeros(n, np.float32); r = np.zeros(n, np.float32); p5 = np.zeros(n, np.float32); u3 = np.zeros((n, 3), np.float32)
+        self._fn("Math")(_p(a), _p(b), C.c_int(n), _p(q), _p(r), _p(p5), _p(u3))
+        return q, r, p5, u3

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <float.h>
 #include <stdint.h>
 
 #include "../../include/rt_types.h"
@@ -15,6 +16,11 @@
 namespace rtd {
 
 struct f3 { float x, y, z; };
+
+// IEEE-754 correctly rounded square root (llvm.sqrt.f32 under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  NOT __fsqrt_rn: in this ROCm that intrinsic is
+// __ocml_native_sqrt_f32 (v_sqrt_f32, 1 ulp) and breaks bit-parity with the CPU.
+__device__ __forceinline__ float rt_sqrt(float x) { return __builtin_sqrtf(x); }
 
 __device__ __forceinline__ f3 F3(float x, float y, float z) { return { x, y, z }; }
 __device__ __forceinline__ f3 ld3(const rt_vec3& v) { return { v.e[0], v.e[1], v.e[2] }; }
@@ -29,7 +35,7 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {                               
     return { (a.y * b.z - a.z * b.y), (-(a.x * b.z - a.z * b.x)), (a.x * b.y - a.y * b.x) };
 }
 __device__ __forceinline__ float sqlen(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }             // vec3.h:36
-__device__ __forceinline__ float len(f3 a) { return __fsqrt_rn(a.x * a.x + a.y * a.y + a.z * a.z); }   // vec3.h:35
+__device__ __forceinline__ float len(f3 a) { return rt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }   // vec3.h:35
 __device__ __forceinline__ f3 unit(f3 a) { return a / len(a); }                                        // vec3.h:194
 __device__ __forceinline__ float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }                    // vec3.h:113
 
@@ -107,7 +113,7 @@ __device__ __forceinline__ f3 refract(f3 uv, f3 n, float etai_over_etat) { // ma
     const float cos_theta = fminf(dot(-uv, n), 1.0f);
     const f3 r_out_parallel = etai_over_etat * (uv + cos_theta * n);
     const float sl = sqlen(r_out_parallel);
-    const f3 r_out_perp = sl >= 1.0f ? F3(0, 0, 0) : (-__fsqrt_rn(1.0f - sl)) * n;
+    const f3 r_out_perp = sl >= 1.0f ? F3(0, 0, 0) : (-rt_sqrt(1.0f - sl)) * n;
     return r_out_parallel + r_out_perp;
 }
 __device__ __forceinline__ f3 reflect(f3 v, f3 n) {                        // material.h:23-25
@@ -126,39 +132,44 @@ struct Scatter {        // scatter_info, helper_structs.h:38-46
 // `normal` faces the ray; `inside` is the path's inside flag; `wo` the un-renormalised path direction.
 __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 normal, bool inside, f3 wo,
                                                  int type, f3 color, float param, uint32_t& rng) {
-    out.specular = false;
-    out.throughput = F3(1.0f, 1.0f, 1.0f);
-    out.refracted = false;
-    out.t = hit_t;
+    // Throughput of every branch is either `color` or (1,1,1):
+    //   DIFFUSE  throughput = albedo                                   (material.h:29)
+    //   METAL    throughput = (1,1,1) * tint                           (material.h:51; 1*x == x exactly)
+    //   GLASS    throughput = exp(-0 * t) = (1,1,1) when inside        (material.h:77, absorption 0:
+    //            expf(-0.0f * t) == 1 for every finite t), then * tint only on the reflected branch (:80-82)
+    // so it is selected ONCE at the end from `refracted`.  (Written per branch as
+    // `out.throughput = out.throughput * color`, hipcc 7.2 dropped the x component of the product in
+    // the glass-reflect branch; tests/test_gpu_probe_functions.py::test_material_scatter pins this.)
+    (void)inside;
+    bool specular, refracted = false;
+    f3 v;                                            // un-normalised outgoing direction
     if (type == RT_DIFFUSE) {
-        out.wi = unit(normal + random_in_unit_sphere(rng));
-        out.throughput = color;
+        v = normal + random_in_unit_sphere(rng);     // material.h:28
+        specular = false;
     } else if (type == RT_METAL) {
-        f3 reflected = reflect(wo, normal);
-        if (param > 0.0001f) reflected = reflected + param * random_in_unit_sphere(rng);
-        out.wi = unit(reflected);
-        out.throughput = out.throughput * color;
-        out.specular = true;
+        v = reflect(wo, normal);                     // material.h:47-50
+        if (param > 0.0001f) v = v + param * random_in_unit_sphere(rng);
+        specular = true;
     } else {
-        // dielectric_bsdf(ior = param, tint = color, fuzz 0, absorption 0)
-        if (inside) {
-            // exp(-absorption * t) with absorption == 0: expf(-0.0f * t) == 1 for every finite t (material.h:77)
-            out.throughput = F3(1.0f, 1.0f, 1.0f);
-        }
+        // dielectric_bsdf(ior = param, tint = color, fuzz 0, absorption 0), material.h:73-92 + fresnel_layer :55-60
         const float etai_over_etat = inside ? param : (1.0f / param);
         const float cos_theta = fminf(dot(-wo, normal), 1.0f);
-        const float sin_theta = __fsqrt_rn(1.0f - cos_theta * cos_theta);
+        const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
         bool reflect_it = etai_over_etat * sin_theta > 1.0f;
         if (!reflect_it) reflect_it = rnd(rng) < schlick(cos_theta, etai_over_etat);
         if (reflect_it) {
-            out.wi = unit(reflect(wo, normal));      // glossy_bsdf with fuzz 0
-            out.throughput = out.throughput * color;
+            v = reflect(wo, normal);                 // glossy_bsdf with fuzz 0
         } else {
-            out.wi = unit(refract(wo, normal, etai_over_etat));
-            out.refracted = true;
+            v = refract(wo, normal, etai_over_etat);
+            refracted = true;
         }
-        out.specular = true;
+        specular = true;
     }
+    out.wi = unit(v);
+    out.throughput = refracted ? F3(1.0f, 1.0f, 1.0f) : color;
+    out.specular = specular;
+    out.refracted = refracted;
+    out.t = hit_t;
 }
 
 // Sky, kernels.cu:419-421 (gradient) / :424 (constant grey)
@@ -169,5 +180,81 @@ __device__ __forceinline__ f3 sky_color(int sky_mode, f3 rayDir) {
     }
     return F3(0.5f, 0.5f, 0.5f);
 }
+
+// ---- ray.h / intersections.h --------------------------------------------------------------------
+
+struct Ray {
+    f3 o, d, inv;       // origin, unit direction, 1/direction
+};
+
+__device__ __forceinline__ Ray make_ray(f3 o, f3 dir) {     // ray.h:9 + the hoisted invD of intersections.h:28
+    Ray r;
+    r.o = o;
+    r.d = unit(dir);
+    r.inv = F3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    return r;
+}
+
+// one axis of the slab test, intersections.h:27-36
+__device__ __forceinline__ void slab(float bmin, float bmax, float o, float invD, float& t_min, float& t_max) {
+    float t0 = (bmin - o) * invD;
+    float t1 = (bmax - o) * invD;
+    if (invD < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+}
+
+__device__ __forceinline__ float hit_bbox_dist(f3 bmin, f3 bmax, const Ray& r, float t_max) {  // intersections.h:25-41
+    float t_min = 0.001f;
+    slab(bmin.x, bmax.x, r.o.x, r.inv.x, t_min, t_max);
+    slab(bmin.y, bmax.y, r.o.y, r.inv.y, t_min, t_max);
+    slab(bmin.z, bmax.z, r.o.z, r.inv.z, t_min, t_max);
+    return (t_max < t_min) ? FLT_MAX : t_min;
+}
+
+// The early-out of the reference matters for ONE thing: a NaN produced on a later axis (0 * inf)
+// can only appear after an earlier axis already failed... it cannot un-fail the test, because NaN
+// compares false and leaves t_min/t_max unchanged.  So the branch-free form is exact.
+__device__ __forceinline__ bool hit_bbox(f3 bmin, f3 bmax, const Ray& r, float t_max) {        // intersections.h:7-23
+    return hit_bbox_dist(bmin, bmax, r, t_max) != FLT_MAX;
+}
+
+// triangleHit, intersections.h:54-83.  `1.0 / a` there is a double divide narrowed to float, which
+// equals the correctly rounded float quotient (53 >= 2*24+2), so 1.0f / a is bit-identical.
+__device__ __forceinline__ float triangle_hit(f3 v0, f3 v1, f3 v2, const Ray& r, float t_min, float t_max, float& hitU, float& hitV) {
+    const float EPS = 0.0000001f;
+    const f3 edge1 = v1 - v0;
+    const f3 edge2 = v2 - v0;
+    const f3 h = cross(r.d, edge2);
+    const float a = dot(edge1, h);
+    if (a > -EPS && a < EPS) return FLT_MAX;
+    const float f = 1.0f / a;
+    const f3 s = r.o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return FLT_MAX;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(r.d, q);
+    if (v < 0.0f || u + v > 1.0f) return FLT_MAX;
+    const float t = f * dot(edge2, q);
+    if (t > t_min && t < t_max) { hitU = u; hitV = v; return t; }
+    return FLT_MAX;
+}
+
+__device__ __forceinline__ float sphere_hit(f3 center, float radius, const Ray& r, float t_min, float t_max) {   // intersections.h:85-104
+    const f3 oc = r.o - center;
+    const float a = dot(r.d, r.d);
+    const float b = dot(oc, r.d);
+    const float c = dot(oc, oc) - radius * radius;
+    const float discriminant = b * b - a * c;
+    if (discriminant > 0) {
+        const float sq = rt_sqrt(discriminant);
+        float temp = (-b - sq) / a;
+        if (temp < t_max && temp > t_min) return temp;
+        temp = (-b + sq) / a;
+        if (temp < t_max && temp > t_min) return temp;
+    }
+    return FLT_MAX;
+}
+
 
 }  // namespace rtd

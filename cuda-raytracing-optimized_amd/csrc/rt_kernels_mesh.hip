@@ -41,42 +41,6 @@ __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     return (stripe * pt.world + pt.rank) * pt.stripe_rows + (lr - stripe * pt.stripe_rows);
 }
 
-struct Ray {
-    f3 o, d, inv;       // origin, unit direction, 1/direction
-};
-
-__device__ __forceinline__ Ray make_ray(f3 o, f3 dir) {     // ray.h:9 + the hoisted invD of intersections.h:28
-    Ray r;
-    r.o = o;
-    r.d = unit(dir);
-    r.inv = F3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    return r;
-}
-
-// one axis of the slab test, intersections.h:27-36
-__device__ __forceinline__ void slab(float bmin, float bmax, float o, float invD, float& t_min, float& t_max) {
-    float t0 = (bmin - o) * invD;
-    float t1 = (bmax - o) * invD;
-    if (invD < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-    t_min = t0 > t_min ? t0 : t_min;
-    t_max = t1 < t_max ? t1 : t_max;
-}
-
-__device__ __forceinline__ float hit_bbox_dist(f3 bmin, f3 bmax, const Ray& r, float t_max) {  // intersections.h:25-41
-    float t_min = 0.001f;
-    slab(bmin.x, bmax.x, r.o.x, r.inv.x, t_min, t_max);
-    slab(bmin.y, bmax.y, r.o.y, r.inv.y, t_min, t_max);
-    slab(bmin.z, bmax.z, r.o.z, r.inv.z, t_min, t_max);
-    return (t_max < t_min) ? FLT_MAX : t_min;
-}
-
-// The early-out of the reference matters for ONE thing: a NaN produced on a later axis (0 * inf)
-// can only appear after an earlier axis already failed... it cannot un-fail the test, because NaN
-// compares false and leaves t_min/t_max unchanged.  So the branch-free form is exact.
-__device__ __forceinline__ bool hit_bbox(f3 bmin, f3 bmax, const Ray& r, float t_max) {        // intersections.h:7-23
-    return hit_bbox_dist(bmin, bmax, r, t_max) != FLT_MAX;
-}
-
 struct Tri { f3 v0, v1, v2; float tc[6]; int meshID; };
 
 __device__ __forceinline__ Tri load_tri(const rt_triangle* tris, uint32_t id) {
@@ -87,43 +51,6 @@ __device__ __forceinline__ Tri load_tri(const rt_triangle* tris, uint32_t id) {
     t.tc[0] = c.y; t.tc[1] = c.z; t.tc[2] = c.w; t.tc[3] = d.x; t.tc[4] = d.y; t.tc[5] = d.z;
     t.meshID = (int)(__float_as_uint(d.w) & 0xFFu);
     return t;
-}
-
-// triangleHit, intersections.h:54-83.  `1.0 / a` there is a double divide narrowed to float, which
-// equals the correctly rounded float quotient (53 >= 2*24+2), so 1.0f / a is bit-identical.
-__device__ __forceinline__ float triangle_hit(f3 v0, f3 v1, f3 v2, const Ray& r, float t_min, float t_max, float& hitU, float& hitV) {
-    const float EPS = 0.0000001f;
-    const f3 edge1 = v1 - v0;
-    const f3 edge2 = v2 - v0;
-    const f3 h = cross(r.d, edge2);
-    const float a = dot(edge1, h);
-    if (a > -EPS && a < EPS) return FLT_MAX;
-    const float f = 1.0f / a;
-    const f3 s = r.o - v0;
-    const float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return FLT_MAX;
-    const f3 q = cross(s, edge1);
-    const float v = f * dot(r.d, q);
-    if (v < 0.0f || u + v > 1.0f) return FLT_MAX;
-    const float t = f * dot(edge2, q);
-    if (t > t_min && t < t_max) { hitU = u; hitV = v; return t; }
-    return FLT_MAX;
-}
-
-__device__ __forceinline__ float sphere_hit(f3 center, float radius, const Ray& r, float t_min, float t_max) {   // intersections.h:85-104
-    const f3 oc = r.o - center;
-    const float a = dot(r.d, r.d);
-    const float b = dot(oc, r.d);
-    const float c = dot(oc, oc) - radius * radius;
-    const float discriminant = b * b - a * c;
-    if (discriminant > 0) {
-        const float sq = __fsqrt_rn(discriminant);
-        float temp = (-b - sq) / a;
-        if (temp < t_max && temp > t_min) return temp;
-        temp = (-b + sq) / a;
-        if (temp < t_max && temp > t_min) return temp;
-    }
-    return FLT_MAX;
 }
 
 struct TravStats { uint32_t nodes, tests; };
@@ -275,12 +202,12 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) 
                 const f3 sw = unit(lightC - org);
                 const f3 su = unit(cross(fabsf(sw.x) > 0.01f ? F3(0, 1, 0) : F3(1, 0, 0), sw));
                 const f3 sv = cross(sw, su);
-                const float cosAMax = __fsqrt_rn(1.0f - lightR * lightR / sqlen(org - lightC));
+                const float cosAMax = rt_sqrt(1.0f - lightR * lightR / sqlen(org - lightC));
                 if (!isnan(cosAMax)) {
                     const float eps1 = rnd(rng);
                     const float eps2 = rnd(rng);
                     const float cosA = 1.0f - eps1 + eps1 * cosAMax;
-                    const float sinA = __fsqrt_rn(1.0f - cosA * cosA);
+                    const float sinA = rt_sqrt(1.0f - cosA * cosA);
                     const float phi = (float)(2 * M_PI * (double)eps2);
                     // cosf/sinf of the reference: evaluated in fp64 and rounded once (libm vs OCML differ by ulps otherwise)
                     const float cphi = (float)cos((double)phi), sphi = (float)sin((double)phi);

@@ -55,7 +55,7 @@ __device__ __forceinline__ float sphere_hit_exact(float4 s, f3 org, f3 dn, float
     const float c = dot(oc, oc) - s.w;
     const float discriminant = b * b - a * c;
     if (discriminant > 0) {
-        const float sq = __fsqrt_rn(discriminant);
+        const float sq = rt_sqrt(discriminant);
         float temp = (-b - sq) / a;
         if (temp < t_max && temp > t_min) return temp;
         temp = (-b + sq) / a;

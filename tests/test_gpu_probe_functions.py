@@ -1,0 +1,199 @@
+"""GPU parity per FUNCTION of the hot path (SURVEY.md §8a rows a-6 .. a-13): each device function is
+run by itself through the probe C-ABI (include/rt_probe.h) on seeded random + edge-case inputs and
+compared with the CPU oracle.  PARITY build: bit-exact (integer work and IEEE fp32 +,-,*,/,sqrt).
+pow(x,5) is the one libm call on this path: 1 ulp allowed (see rt_device.h pow5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 3000
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+@pytest.fixture(scope="module")
+def probe(rt):
+    return rt.Probe("parity")
+
+
+@pytest.fixture(scope="module")
+def lib(O):
+    return O.load_oracle()
+
+
+def test_basic_math_is_ieee(probe):
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-3, 3, N).astype(np.float32)
+    b = rng.uniform(0.01, 5, N).astype(np.float32) * rng.choice([-1, 1], N).astype(np.float32)
+    q, r, p5, u3 = probe.math(a, b)
+    assert np.array_equal(_bits(q), _bits(a / b))
+    assert np.array_equal(_bits(r), _bits(np.sqrt(np.abs(a))))
+    v = np.stack([a, b, a - b], 1)
+    ln = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
+    assert np.array_equal(_bits(u3), _bits(v / ln[:, None]))
+    exact = (a.astype(np.float64) ** 5).astype(np.float32)
+    assert np.array_equal(_bits(p5), _bits(exact))
+
+
+def test_rng_known_answers(probe, lib):
+    ids = np.array([0, 12345, 1, 959999, 2 ** 31 + 7] + list(range(100, 160)), np.uint32)
+    seed, draws, state = probe.rng(ids)
+    # known answers minted from the reference's rnd.h
+    assert seed[0] == 3202281099 and seed[1] == 2055759875
+    assert np.array_equal(_bits(draws[0]), _bits(np.array([0.538071394, 0.20499754, 0.405853808, 0.0468345881], np.float32)))
+    for k, pid in enumerate(ids):
+        st = C.c_uint32(lib.orc_pixel_seed(int(pid)))
+        assert st.value == seed[k]
+        for q in range(4):
+            assert np.float32(lib.orc_rnd(C.byref(st))) == draws[k, q]
+        assert st.value == state[k]
+
+
+def test_disk_and_sphere_sampling(probe, lib):
+    rng = np.random.default_rng(2)
+    states = (rng.integers(1, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)) | 1
+    states[0] = 2055759875      # pixel 12345 seed
+    disk, sd, sph, ss = probe.disk_sphere(states)
+    out = (C.c_float * 3)()
+    for k in range(N):
+        st = C.c_uint32(int(states[k]))
+        lib.orc_random_in_unit_disk(C.byref(st), out)
+        assert np.array_equal(_bits(disk[k]), _bits(np.array(out[:], np.float32))) and st.value == sd[k]
+        st = C.c_uint32(int(states[k]))
+        lib.orc_random_in_unit_sphere(C.byref(st), out)
+        assert np.array_equal(_bits(sph[k]), _bits(np.array(out[:], np.float32))) and st.value == ss[k]
+
+
+@pytest.mark.parametrize("scene", ["c1", "c2"])
+def test_get_ray(rt, probe, lib, scene):
+    nx, ny = (400, 200) if scene == "c1" else (1200, 800)
+    _, _, cam = rt.scene_three_spheres(nx, ny) if scene == "c1" else rt.scene_random_spheres(nx, ny)
+    rng = np.random.default_rng(3)
+    s = rng.uniform(0, 1, N).astype(np.float32)
+    t = rng.uniform(0, 1, N).astype(np.float32)
+    states = (rng.integers(1, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)) | 1
+    org, d, sa = probe.get_ray(cam, s, t, states)
+    o_ = (C.c_float * 3)(); d_ = (C.c_float * 3)()
+    for k in range(N):
+        st = C.c_uint32(int(states[k]))
+        lib.orc_get_ray(C.byref(cam), float(s[k]), float(t[k]), C.byref(st), o_, d_)
+        assert np.array_equal(_bits(org[k]), _bits(np.array(o_[:], np.float32))), k
+        assert np.array_equal(_bits(d[k]), _bits(np.array(d_[:], np.float32))), k
+        assert st.value == sa[k]
+
+
+def _rays(rng, n):
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    return org, d
+
+
+def test_sphere_hit(rt, probe, lib):
+    rng = np.random.default_rng(4)
+    sp = np.zeros(N, rt.sphere_dtype)
+    sp["center"] = rng.uniform(-2, 2, (N, 3))
+    sp["radius"] = rng.uniform(0.1, 2.5, N)
+    org, d = _rays(rng, N)
+    # edge cases: origin inside the sphere, grazing rays, huge ground sphere, t window that cuts the near root
+    org[:300] = sp["center"][:300] + rng.uniform(-0.05, 0.05, (300, 3)).astype(np.float32)
+    sp["center"][300:400] = (0, -1000, -1); sp["radius"][300:400] = 1000
+    org[300:400, 1] = np.abs(org[300:400, 1]) * 0.01
+    for k in range(400, 700):           # aim exactly at the limb
+        c = sp["center"][k]; r = sp["radius"][k]
+        to = c - org[k]; perp = np.cross(to, [0.3, 0.9, 0.1]); perp /= np.linalg.norm(perp)
+        d[k] = (to + perp * r).astype(np.float32)
+    tmin = np.full(N, 0.001, np.float32); tmin[700:900] = 0.01
+    tmax = np.full(N, np.finfo(np.float32).max, np.float32); tmax[900:1400] = rng.uniform(0.5, 4, 500)
+    got = probe.sphere_hit(sp, org, d, tmin, tmax)
+    exp = np.array([lib.orc_sphere_hit(C.byref(rt.sphere.from_buffer_copy(sp[k].tobytes())), _f3(org[k]), _f3(d[k]),
+                                       float(tmin[k]), float(tmax[k])) for k in range(N)], np.float32)
+    assert np.array_equal(_bits(got), _bits(exp)), np.count_nonzero(_bits(got) != _bits(exp))
+    assert (exp < 1e30).sum() > 300        # the table does exercise hits
+
+
+def test_triangle_hit(rt, probe, lib):
+    rng = np.random.default_rng(5)
+    tr = np.zeros(N, rt.triangle_dtype)
+    tr["v"] = rng.uniform(-2, 2, (N, 3, 3))
+    org, d = _rays(rng, N)
+    for k in range(0, 1500):            # aim at a point inside / on an edge / at a vertex of the triangle
+        w = rng.dirichlet([1, 1, 1]) if k < 1000 else (np.array([0.5, 0.5, 0.0]) if k < 1250 else np.array([1.0, 0.0, 0.0]))
+        target = (tr["v"][k] * w[:, None]).sum(0)
+        d[k] = (target - org[k]).astype(np.float32)
+    d[1500:1600] = tr["v"][1500:1600, 1] - tr["v"][1500:1600, 0]     # parallel to the plane
+    tmin = np.full(N, 0.01, np.float32)
+    tmax = np.full(N, np.finfo(np.float32).max, np.float32); tmax[2000:2500] = rng.uniform(0.5, 4, 500)
+    t, u, v = probe.triangle_hit(tr, org, d, tmin, tmax)
+    hu = C.c_float(); hv = C.c_float()
+    for k in range(N):
+        hu.value = 0.0; hv.value = 0.0
+        e = lib.orc_triangle_hit(C.byref(rt.triangle.from_buffer_copy(tr[k].tobytes())), _f3(org[k]), _f3(d[k]),
+                                 float(tmin[k]), float(tmax[k]), C.byref(hu), C.byref(hv))
+        assert np.float32(e).view(np.uint32) == t[k].view(np.uint32), k
+        if e < 1e30:
+            assert np.float32(hu.value) == u[k] and np.float32(hv.value) == v[k], k
+    assert (t < 1e30).sum() > 500
+
+
+def test_bbox_slab_tests(probe, lib):
+    rng = np.random.default_rng(6)
+    lo = rng.uniform(-2, 1, (N, 3)).astype(np.float32)
+    hi = lo + rng.uniform(0, 2, (N, 3)).astype(np.float32)
+    hi[:200, 1] = lo[:200, 1]                    # flat boxes (axis-aligned quads)
+    org, d = _rays(rng, N)
+    d[200:400, 0] = 0.0                          # axis-parallel rays: 1/0 = inf, 0*inf = NaN inside the slab test
+    d[400:500, 2] = -0.0
+    org[500:600] = (lo[500:600] + hi[500:600]) / 2   # origin inside the box
+    org[600:700, 0] = lo[600:700, 0]             # origin exactly on a slab plane with dir.x = 0 -> NaN path
+    d[600:700, 0] = 0.0
+    tmax = np.full(N, np.finfo(np.float32).max, np.float32); tmax[1000:2000] = rng.uniform(0.1, 5, 1000)
+    dist, hit = probe.bbox(lo, hi, org, d, tmax)
+    for k in range(N):
+        e = lib.orc_hit_bbox_dist(_f3(lo[k]), _f3(hi[k]), _f3(org[k]), _f3(d[k]), float(tmax[k]))
+        h = lib.orc_hit_bbox(_f3(lo[k]), _f3(hi[k]), _f3(org[k]), _f3(d[k]), float(tmax[k]))
+        assert np.float32(e).view(np.uint32) == dist[k].view(np.uint32), k
+        assert h == hit[k], k
+    assert 100 < hit.sum() < N - 100, hit.sum()
+
+
+def test_material_scatter(rt, O, probe, lib):
+    rng = np.random.default_rng(7)
+    normal = rng.normal(size=(N, 3)); normal /= np.linalg.norm(normal, axis=1)[:, None]
+    wo = rng.normal(size=(N, 3)); wo /= np.linalg.norm(wo, axis=1)[:, None]
+    flip = (wo * normal).sum(1) > 0
+    normal[flip] *= -1                            # the normal always faces the ray (kernels.cu:354)
+    wo[2000:2300] = -normal[2000:2300] * 0.999 + 0.04 * rng.normal(size=(300, 3))     # near-normal incidence
+    wo[2300:2600] -= normal[2300:2600] * (wo[2300:2600] * normal[2300:2600]).sum(1)[:, None] * 0.98  # grazing -> TIR inside
+    mats = np.zeros(N, rt.material_dtype)
+    mats["type"] = np.arange(N) % 3
+    mats["color"] = rng.uniform(0, 1, (N, 3))
+    mats["param"] = np.where(mats["type"] == rt.RT_GLASS, 1.5, np.where(np.arange(N) % 2 == 0, 0.0, rng.uniform(0, 0.5, N)))
+    mats["texId"] = -1
+    inside = (rng.uniform(size=N) < 0.5).astype(np.int32)
+    t = rng.uniform(0.01, 10, N).astype(np.float32)
+    color = mats["color"].astype(np.float32)
+    states = (rng.integers(1, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)) | 1
+    wi, thr, flags, tout, sa = probe.scatter(t, normal, inside, wo, mats, color, states)
+    sc = O.orc_scatter()
+    n32 = normal.astype(np.float32); w32 = wo.astype(np.float32)
+    kinds = set()
+    for k in range(N):
+        st = C.c_uint32(int(states[k]))
+        lib.orc_material_scatter(float(t[k]), _f3(n32[k]), int(inside[k]), _f3(w32[k]),
+                                 C.byref(rt.material.from_buffer_copy(mats[k].tobytes())), _f3(color[k]), C.byref(st), C.byref(sc))
+        assert st.value == sa[k], (k, "rng state")
+        assert flags[k] == (sc.specular | (sc.refracted << 1)), k
+        assert np.array_equal(_bits(wi[k]), _bits(np.array(sc.wi[:], np.float32))), (k, int(mats["type"][k]))
+        assert np.array_equal(_bits(thr[k]), _bits(np.array(sc.throughput[:], np.float32))), k
+        assert np.float32(sc.t) == tout[k]
+        kinds.add((int(mats["type"][k]), int(flags[k])))
+    assert (rt.RT_GLASS, 3) in kinds and (rt.RT_GLASS, 1) in kinds and (rt.RT_METAL, 1) in kinds and (rt.RT_DIFFUSE, 0) in kinds
