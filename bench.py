@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the render() hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--fp parity|fast]
+
+A "step" is one full frame of the workload rendered through the C-ABI
+(initRendererSpheres once, then runRenderer per step; scene and camera already resident in HBM).
+
+  N = 1   BASELINE.json configs[1]: random-spheres (488 spheres), 1200x800, 100 spp, maxDepth 50.
+  N > 1   weak scaling: the same scene, 100 spp, 3:2 image whose AREA grows with N (~960 k pixels per
+          GPU); the image is cut into interleaved 8-row stripes, rank r renders stripes k = r (mod N)
+          (no collective on the data path) and the stripes are gathered on the host into one shared
+          framebuffer (plain memcpy through /dev/shm).  Launched by the driver as
+          `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SPP = 100
+MAX_DEPTH = 50
+N_SPHERES = 488
+PEAK_FP32_VALU_TFLOPS = 157.3       # MI355X vector fp32 peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)"
+FLOPS_PER_TEST = 18                 # sphereHit discriminant path with `a` hoisted
+FLOPS_PER_RAY = 80                  # per-ray set-up + shading
+
+
+def image_size(n_gpus):
+    """3:2 image with ~960 k pixels per GPU, both sides multiples of 8."""
+    if n_gpus == 1:
+        return 1200, 800
+    nx = int(round(1200 * n_gpus ** 0.5 / 8.0)) * 8
+    ny = int(round(nx * 2 / 3 / 8.0)) * 8
+    return nx, ny
+
+
+def cpu_baseline(rt, nx, ny):
+    """The reference's own header-only code as a single-threaded host loop (oracle/_ref), or our C
+    restatement of it when the shim is absent, timed on a bounded sample of the SAME workload:
+    the full 1200x800 frame, first CPU_SPP samples of every pixel stream."""
+    from oracle import oracle as O
+    cpu_spp = int(os.environ.get("RT_BENCH_CPU_SPP", "4"))
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    opt = O.default_options(True)
+    t0 = time.perf_counter()
+    if O.have_ref():
+        O.ref_render_spheres(sp, mt, cam, opt, nx, ny, cpu_spp, MAX_DEPTH)
+        kind = "reference"
+    else:
+        O.render(O.sphere_scene(sp, mt), cam, opt, nx, ny, cpu_spp, MAX_DEPTH)
+        kind = "port"
+    dt = time.perf_counter() - t0
+    samples = nx * ny * cpu_spp
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": f"{nx}x{ny} full frame, first {cpu_spp} spp of every pixel stream "
+                      f"({samples / 1e6:.2f} M of the {nx * ny * SPP / 1e6:.0f} M samples), {dt:.1f} s single-threaded",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--fp", choices=["parity", "fast"], default=os.environ.get("RT_BENCH_FP", "parity"))
+    ap.add_argument("--variant", type=int, default=int(os.environ.get("RT_BENCH_VARIANT", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import cuda_raytracing_optimized_amd as rt
+
+    nx, ny = image_size(world)
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, MAX_DEPTH)
+    opt = rt.getDefaultRenderOptions(True)
+    fp = rt.RT_FP_FAST if args.fp == "fast" else rt.RT_FP_PARITY
+    rt.setRenderOptions(opt, fp=fp, variant=args.variant, part_rank=rank, part_world=world, stripe_rows=8)
+
+    # host gather target: one framebuffer shared by all ranks of the node
+    shared = None
+    if world > 1:
+        path = f"/dev/shm/rt_bench_fb_{os.environ.get('MASTER_PORT', '0')}.f32"
+        if rank == 0:
+            np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(ny, nx, 3)).flush()
+        dist.barrier()
+        shared = np.load(path, mmap_mode="r+")
+    nstripes = (ny + 7) // 8
+    my_rows = np.concatenate([np.arange(k * 8, min(ny, k * 8 + 8)) for k in range(rank, nstripes, world)])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        rt.runRenderer(SPP, 8, 8)                # blocking: kernel + D2H of this rank's stripes
+        if shared is not None:
+            shared[my_rows] = fb[my_rows]        # host-side gather (no RCCL)
+
+    # one counted run (untimed): rays per frame for the algorithmic flop count
+    rt.setRenderOptions(opt, counters=1)
+    step()
+    rays_local = rt.getRenderStats().rays
+    rt.setRenderOptions(opt, counters=0)
+    for _ in range(args.warmup):
+        step()
+
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(rt.getRenderStats().kernel_ms)
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(rays_local)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, kern_ms_max, rays_total = tmax[0].item(), tmax[1].item(), tsum[2].item()
+    else:
+        elapsed, kern_ms_max, rays_total = stats[0].item(), stats[1].item(), stats[2].item()
+
+    if rank == 0:
+        total_samples = nx * ny * SPP
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_samples * args.steps / elapsed / 1e6
+        # roofline of the dominant (only) kernel, per launch on one GPU
+        rays_per_gpu = rays_total / world
+        flops_per_launch = rays_per_gpu * (FLOPS_PER_TEST * N_SPHERES + FLOPS_PER_RAY)
+        achieved = flops_per_launch / (kern_ms_max * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/s (pixels x spp / s), random-spheres 1200x800x100spp",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"random-spheres (488 spheres, LCG seed 0) {nx}x{ny} {SPP}spp maxDepth {MAX_DEPTH}, "
+                                   f"gradient sky, reference RNG stream, fp {args.fp}",
+                       "image": [nx, ny], "spp": SPP, "max_depth": MAX_DEPTH, "spheres": N_SPHERES,
+                       "partition": f"{world} x interleaved 8-row stripes, host gather" if world > 1 else "single GPU",
+                       "fp_mode": args.fp, "kernel_variant": args.variant},
+            "frame_ms_kernel": kern_ms_max,
+            "rays_per_sample": rays_total / total_samples,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "k_render_spheres", "kernel_ms_avg": kern_ms_max,
+                         "flops_per_launch": flops_per_launch,
+                         "note": "fp32 VALU bound (no MFMA, HBM traffic ~12 B/pixel/frame); algorithmic flops = "
+                                 "rays x (18 x 488 + 80), rays counted on the GPU (bit-equal to the oracle's count)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, nx, ny)
+        print(json.dumps(out), flush=True)
+
+    rt.cleanupRenderer()
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
