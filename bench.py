@@ -75,7 +75,11 @@ def main():
     ap.add_argument("--fp", choices=["parity", "fast"], default=os.environ.get("RT_BENCH_FP", "parity"))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RT_BENCH_VARIANT", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=SPP, help="experiments only; the contract workload is 100")
+    ap.add_argument("--max-depth", type=int, default=MAX_DEPTH, help="experiments only; the contract workload is 50")
     args = ap.parse_args()
+    globals()["SPP"] = args.spp
+    globals()["MAX_DEPTH"] = args.max_depth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

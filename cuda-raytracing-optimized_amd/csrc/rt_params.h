@@ -29,7 +29,7 @@ struct RtSphereParams {
     rt_camera cam;
     int32_t nx, ny, ns, max_depth;
     int32_t n;                  // spheres
-    int32_t n_padded;           // multiple of 32 (pad entries can never be hit)
+    int32_t n_padded;           // multiple of 64 (pad entries can never be hit)
     const float4* spheres;      // n_padded x (cx, cy, cz, radius)
     const float4* mat_color;    // n x (r, g, b, param)
     const int32_t* mat_type;    // n
@@ -40,6 +40,9 @@ struct RtSphereParams {
     int32_t rng_mode;
     float   t_min;
     RtCounters* counters;       // nullptr = off
+    uint32_t* queue;            // one zero-initialised word: next unassigned pixel (persistent-wave kernels)
+    unsigned long long* wave_dbg;   // nullptr, or 8 x u64 per wave: diagnostic time stamps (RT_WAVE_DEBUG)
+    uint32_t* order;            // 2 * padded pixel count words: work-order lists built by the classify pre-pass
 };
 
 struct RtMeshParams {
@@ -64,6 +67,7 @@ struct RtMeshParams {
     rt_sphere light;
     rt_vec3 lightColor;
     RtCounters* counters;
+    uint32_t* queue;
 };
 
 // LDS the sphere kernel needs for a scene of n spheres with `threads` threads per workgroup.

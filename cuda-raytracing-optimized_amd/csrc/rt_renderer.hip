@@ -59,6 +59,9 @@ struct DeviceState {
     rt_vec3* d_fb = nullptr;
     size_t fb_rows = 0;
     RtCounters* d_counters = nullptr;
+    uint32_t* d_queue = nullptr;
+    unsigned long long* d_wave_dbg = nullptr;
+    uint32_t* d_order = nullptr;
 };
 
 struct RenderContext {
@@ -114,7 +117,7 @@ void free_device(DeviceState& d) {
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
-    fr(d.d_fb); fr(d.d_counters);
+    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order);
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
     if (d.ev_stop) HIP_CHECK(hipEventDestroy(d.ev_stop));
     if (d.stream) HIP_CHECK(hipStreamDestroy(d.stream));
@@ -177,8 +180,14 @@ void setup_devices() {
         const int world = c.opt.part_world * nd, rank = c.opt.part_rank * nd + k;
         d.fb_rows = (size_t)local_rows_of(c.ny, c.opt.stripe_rows, rank, world);
         if (d.fb_rows > 0) HIP_CHECK(hipMalloc((void**)&d.d_fb, d.fb_rows * c.nx * sizeof(rt_vec3)));
+        if (d.fb_rows > 0) {        // work-order lists of the persistent kernels: 2 x (pixels padded to 8x8 tiles)
+            const size_t padded = (size_t)((c.nx + 7) / 8) * ((d.fb_rows + 7) / 8) * 64;
+            HIP_CHECK(hipMalloc((void**)&d.d_order, 2 * padded * sizeof(uint32_t)));
+        }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
         HIP_CHECK(hipMemset(d.d_counters, 0, sizeof(RtCounters)));
+        HIP_CHECK(hipMalloc((void**)&d.d_queue, 64));
+        HIP_CHECK(hipMemset(d.d_queue, 0, 64));
         c.devs.push_back(d);
     }
     HIP_CHECK(hipSetDevice(current));
@@ -277,7 +286,7 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
     c.is_spheres = true;
     default_options(&c.opt, 1);
     c.n_spheres = n;
-    c.n_padded = (n + 31) & ~31;
+    c.n_padded = (n + 63) & ~63;                // multiple of 64: one sphere per lane per round in the cooperative scan
     // pad entries: radius 0 far away; additionally the kernel never accepts an index >= n
     c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));
     c.h_mat_color.resize(n);
@@ -342,6 +351,15 @@ void runRenderer(int ns, int tx, int ty) {
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
+            p.queue = d.d_queue;
+            p.order = d.d_order;
+            static const char* dbg_path = getenv("RT_WAVE_DEBUG");      // diagnostics: per-wave time stamps -> file
+            const size_t dbg_bytes = (size_t)65536 * 8 * sizeof(unsigned long long);
+            if (dbg_path) {
+                if (!d.d_wave_dbg) HIP_CHECK(hipMalloc((void**)&d.d_wave_dbg, dbg_bytes));
+                HIP_CHECK(hipMemsetAsync(d.d_wave_dbg, 0, dbg_bytes, d.stream));
+                p.wave_dbg = d.d_wave_dbg;
+            }
             if (c.opt.nee) rt_fail("runRenderer: next-event estimation is only defined for mesh scenes");
             HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream)
                                              : rt_launch_spheres_parity(p, c.opt.variant, d.stream));
@@ -358,6 +376,7 @@ void runRenderer(int ns, int tx, int ty) {
             p.sky = c.opt.sky; p.nee = c.opt.nee; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.light = c.opt.light; p.lightColor = c.opt.lightColor;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
+            p.queue = d.d_queue;
             HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_mesh_fast(p, c.opt.variant, d.stream)
                                              : rt_launch_mesh_parity(p, c.opt.variant, d.stream));
             launches++;
@@ -390,6 +409,11 @@ void runRenderer(int ns, int tx, int ty) {
         float ms = 0.0f;
         HIP_CHECK(hipEventElapsedTime(&ms, d.ev_start, d.ev_stop));
         kernel_ms = std::max(kernel_ms, (double)ms);
+        if (d.d_wave_dbg && getenv("RT_WAVE_DEBUG")) {
+            std::vector<unsigned long long> h((size_t)65536 * 8);
+            HIP_CHECK(hipMemcpy(h.data(), d.d_wave_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(getenv("RT_WAVE_DEBUG"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+        }
         if (c.opt.counters) {
             RtCounters h;
             HIP_CHECK(hipMemcpy(&h, d.d_counters, sizeof h, hipMemcpyDeviceToHost));

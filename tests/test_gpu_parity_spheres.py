@@ -31,11 +31,14 @@ def test_c1_three_spheres_bit_exact(rt, O, nx, ny, ns):
     assert st.rays == cnt.rays and st.prim_tests == cnt.prim_tests
 
 
-@pytest.mark.parametrize("nx,ny,ns", [(300, 200, 2), (120, 80, 8)])
-def test_random_spheres_bit_exact(rt, O, nx, ny, ns):
+# kernel variants (rt_kernels_spheres.hip): 0 = persistent waves + pixel queue (default), 1 = one tile per wave;
+# bits 8..15 workgroups per CU, bits 16..23 cooperative-scan threshold, bits 24..25 work order (see the launcher)
+@pytest.mark.parametrize("variant", [0, 1, (1 << 8), (8 << 8), (1 << 24), (2 << 24), (65 << 16), (1 << 16) + 1])
+@pytest.mark.parametrize("nx,ny,ns", [(300, 200, 2), (120, 80, 8), (61, 37, 5)])
+def test_random_spheres_bit_exact(rt, O, nx, ny, ns, variant):
     sp, mt, cam = rt.scene_random_spheres(nx, ny)
     ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50, counters=True)
-    got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, counters=1)
+    got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, counters=1, variant=variant)
     assert np.array_equal(_bits(got), _bits(ref)), f"{np.count_nonzero(_bits(got) != _bits(ref))} differing words"
     assert st.rays == cnt.rays
 

@@ -1,0 +1,38 @@
+"""Reads the RT_WAVE_DEBUG dump (8 x u64 per wave) and prints a time line of the persistent kernel."""
+import sys
+import numpy as np
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+a = a[a[:, 7] == 1]
+t0 = a[:, 0].min()
+start = (a[:, 0] - t0) / 1e5      # ms (100 MHz)
+tex = np.where(a[:, 1] > 0, (a[:, 1].astype(np.int64) - int(t0)) / 1e5, np.nan)
+end = (a[:, 2] - t0) / 1e5
+print("waves", len(a), "kernel span ms %.2f" % end.max())
+print("start   ms: min %.2f max %.2f" % (start.min(), start.max()))
+print("exhaust ms: min %.2f median %.2f max %.2f" % (np.nanmin(tex), np.nanmedian(tex), np.nanmax(tex)))
+print("end     ms: p10 %.2f median %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(end, [10, 50, 90, 99, 100])))
+print("iterations per wave: mean %.0f max %d | coop iterations: mean %.0f max %d | coop rays mean %.0f max %d" %
+      (a[:, 3].mean(), a[:, 3].max(), a[:, 4].mean(), a[:, 4].max(), a[:, 5].mean(), a[:, 5].max()))
+hist, edges = np.histogram(end, bins=20)
+for h, e in zip(hist, edges):
+    print("  end in [%6.2f, ..) ms: %5d waves" % (e, h))
+late = np.argsort(end)[-5:]
+for w in late:
+    print("  late wave: end %.2f exhausted %.2f iters %d coop_iters %d coop_rays %d" % (end[w], tex[w], a[w, 3], a[w, 4], a[w, 5]))
+
+early = end < 1.0
+print("early waves:", early.sum(), "their iters: mean %.1f max %d" % (a[early, 3].mean() if early.any() else 0, a[early, 3].max() if early.any() else 0))
+hw = a[:, 6]
+xcc = (hw >> np.uint64(32)) & np.uint64(0xF)
+hwid = hw & np.uint64(0xFFFFFFFF)
+# gfx9 HW_ID: wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13] (se_id 3 bits on gfx90a+)
+cu = (hwid >> np.uint64(8)) & np.uint64(0xF)
+sh = (hwid >> np.uint64(12)) & np.uint64(0x1)
+se = (hwid >> np.uint64(13)) & np.uint64(0x7)
+simd = (hwid >> np.uint64(4)) & np.uint64(0x3)
+key = (xcc.astype(np.int64) * 8 + se.astype(np.int64)) * 32 + sh.astype(np.int64) * 16 + cu.astype(np.int64)
+uk, cnt = np.unique(key, return_counts=True)
+print("distinct CUs used:", len(uk), "waves per CU: min %d max %d" % (cnt.min(), cnt.max()), "histogram", np.bincount(cnt))
+for c in sorted(set(cnt)):
+    sel = np.isin(key, uk[cnt == c])
+    print("  CUs with %2d waves: %4d waves, median end %.1f ms, median exhausted %.1f" % (c, sel.sum(), np.median(end[sel]), np.nanmedian(tex[sel]) if np.isfinite(tex[sel]).any() else -1))
