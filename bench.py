@@ -35,15 +35,6 @@ FLOPS_PER_TEST = 18                 # sphereHit discriminant pat
 FLOPS_PER_RAY = 80                  # per-ray set-up + shading
 
 
-def image_size(n_gpus):
-    """3:2 image with ~960 k pixels per GPU, both sides multiples of 8."""
-    if n_gpus == 1:
-        return 1200, 800
-    nx = int(round(1200 * n_gpus ** 0.5 / 8.0)) * 8
-    ny = int(round(nx * 2 / 3 / 8.0)) * 8
-    return nx, ny
-
-
 def cpu_baseline(rt, nx, ny):
     """The reference's own header-only code as a single-threaded host loop (oracle/_ref), or our C
     restatement of it when the shim is absent, timed on a bounded sample of the SAME workload:
@@ -99,8 +90,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import cuda_raytracing_optimized_amd as rt
+    from cuda_raytracing_optimized_amd import multigpu
 
-    nx, ny = image_size(world)
+    nx, ny = multigpu.image_size(world)
     sp, mt, cam = rt.scene_random_spheres(nx, ny)
     fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, MAX_DEPTH)
     opt = rt.getDefaultRenderOptions(True)
@@ -110,13 +102,8 @@ def main():
     # host gather target: one framebuffer shared by all ranks of the node
     shared = None
     if world > 1:
-        path = f"/dev/shm/rt_bench_fb_{os.environ.get('MASTER_PORT', '0')}.f32"
-        if rank == 0:
-            np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(ny, nx, 3)).flush()
-        dist.barrier()
-        shared = np.load(path, mmap_mode="r+")
-    nstripes = (ny + 7) // 8
-    my_rows = np.concatenate([np.arange(k * 8, min(ny, k * 8 + 8)) for k in range(rank, nstripes, world)])
+        shared = multigpu.SharedFramebuffer(f"bench_{os.environ.get('MASTER_PORT', '0')}", nx, ny, rank, dist.barrier)
+    my_rows = multigpu.stripe_rows(rank, world, ny)
 
     def sync():
         if world > 1:
@@ -126,7 +113,7 @@ def main():
     def step():
         rt.runRenderer(SPP, 8, 8)                # blocking: kernel + D2H of this rank's stripes
         if shared is not None:
-            shared[my_rows] = fb[my_rows]        # host-side gather (no RCCL)
+            shared.gather(fb, my_rows)           # host-side gather (no RCCL)
 
     # one counted run (untimed): rays per frame for the algorithmic flop count
     rt.setRenderOptions(opt, counters=1)
@@ -188,12 +175,7 @@ def main():
 
     rt.cleanupRenderer()
     if world > 1:
-        dist.barrier()
-        if rank == 0:
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+        shared.close(dist.barrier)
         dist.destroy_process_group()
 
 

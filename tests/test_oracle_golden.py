@@ -1,0 +1,154 @@
+"""CPU: the plain-C oracle (oracle/rt_oracle.c) against the golden vectors in tests/golden/, which were minted
+from the reference's own headers by oracle/gen_golden.py.  Everything here is bit-exact."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+@pytest.fixture(scope="module")
+def lib(O):
+    return O.load_oracle()
+
+
+def test_rng_known_answers_from_survey(lib):
+    """SURVEY.md §8c KATs (computed there from rnd.h under g++ and clang)."""
+    assert lib.orc_pixel_seed(0) == 3202281099
+    st = C.c_uint32(3202281099)
+    states = [lib.orc_xor_shift_32(C.byref(st)) for _ in range(4)]
+    assert states == [3163143948, 3056892600, 2322064905, 135003482]
+    st = C.c_uint32(3202281099)
+    draws = np.array([lib.orc_rnd(C.byref(st)) for _ in range(4)], np.float32)
+    assert np.array_equal(draws, np.array([0.538071394, 0.20499754, 0.405853808, 0.0468345881], np.float32))
+    assert lib.orc_pixel_seed(12345) == 2055759875
+    out = (C.c_float * 3)()
+    st = C.c_uint32(2055759875)
+    lib.orc_random_in_unit_disk(C.byref(st), out)
+    assert np.array_equal(np.array(out[:], np.float32), np.array([-0.158576131, 0.909173727, 0], np.float32)) and st.value == 3086245838
+    st = C.c_uint32(2055759875)
+    lib.orc_random_in_unit_sphere(C.byref(st), out)
+    assert np.array_equal(np.array(out[:], np.float32), np.array([-0.104780674, -0.891498923, -0.365709543], np.float32))
+    assert st.value == 4266733678
+
+
+def test_rng_tables(lib):
+    g = np.load(os.path.join(G, "rng.npz"))
+    for k, pid in enumerate(g["pixel_ids"]):
+        assert lib.orc_pixel_seed(int(pid)) == g["seeds"][k]
+        st = C.c_uint32(int(g["seeds"][k]))
+        for q in range(8):
+            assert np.float32(lib.orc_rnd(C.byref(st))) == g["draws"][k, q] and st.value == g["states"][k, q]
+    out = (C.c_float * 3)()
+    for k, s in enumerate(g["st_in"]):
+        st = C.c_uint32(int(s)); lib.orc_random_in_unit_disk(C.byref(st), out)
+        assert np.array_equal(_bits(np.array(out[:])), _bits(g["disk"][k])) and st.value == g["st_disk"][k]
+        st = C.c_uint32(int(s)); lib.orc_random_in_unit_sphere(C.byref(st), out)
+        assert np.array_equal(_bits(np.array(out[:])), _bits(g["sphere"][k])) and st.value == g["st_sphere"][k]
+
+
+def test_camera_and_get_ray(rt, lib):
+    g = np.load(os.path.join(G, "camera.npz"))
+    o_ = (C.c_float * 3)(); d_ = (C.c_float * 3)()
+    for k, ci in enumerate(g["cam_in"]):
+        cam = rt.camera()
+        lib.orc_make_camera(f3(ci[0:3]), f3(ci[3:6]), f3(ci[6:9]), float(ci[9]), float(ci[10]), float(ci[11]), float(ci[12]), C.byref(cam))
+        assert np.array_equal(_bits(np.frombuffer(bytes(cam), np.float32)), _bits(g["cam_out"][k])), k
+        # the product's host-side constructor (librt_host.so) must give the same bits
+        cam2 = rt.make_camera(ci[0:3], ci[3:6], ci[6:9], float(ci[9]), float(ci[10]), float(ci[11]), float(ci[12]))
+        assert bytes(cam2) == bytes(cam)
+        for q in range(g["s"].shape[1]):
+            st = C.c_uint32(int(g["st_in"][k, q]))
+            lib.orc_get_ray(C.byref(cam), float(g["s"][k, q]), float(g["t"][k, q]), C.byref(st), o_, d_)
+            assert np.array_equal(_bits(np.array(o_[:])), _bits(g["org"][k, q]))
+            assert np.array_equal(_bits(np.array(d_[:])), _bits(g["dir"][k, q]))
+            assert st.value == g["st_out"][k, q]
+
+
+def test_intersections(rt, lib):
+    g = np.load(os.path.join(G, "intersections.npz"))
+    n = len(g["s_t"])
+    got = np.array([lib.orc_sphere_hit(C.byref(rt.sphere.from_buffer_copy(g["spheres"][k].tobytes())), f3(g["s_org"][k]), f3(g["s_dir"][k]),
+                                       float(g["s_tmin"][k]), float(g["s_tmax"][k])) for k in range(n)], np.float32)
+    assert np.array_equal(_bits(got), _bits(g["s_t"]))
+    assert (g["s_t"] < 1e30).sum() > 50
+    hu = C.c_float(); hv = C.c_float()
+    for k in range(n):
+        hu.value = 0; hv.value = 0
+        t = lib.orc_triangle_hit(C.byref(rt.triangle.from_buffer_copy(g["tris"][k].tobytes())), f3(g["t_org"][k]), f3(g["t_dir"][k]),
+                                 0.01, float(g["t_tmax"][k]), C.byref(hu), C.byref(hv))
+        assert np.float32(t).view(np.uint32) == g["t_t"][k].view(np.uint32), k
+        assert np.float32(hu.value) == g["t_u"][k] and np.float32(hv.value) == g["t_v"][k]
+    assert (g["t_t"] < 1e30).sum() > 100
+    for k in range(n):
+        args = (f3(g["b_lo"][k]), f3(g["b_hi"][k]), f3(g["b_org"][k]), f3(g["b_dir"][k]), float(g["b_tmax"][k]))
+        assert np.float32(lib.orc_hit_bbox_dist(*args)).view(np.uint32) == g["b_dist"][k].view(np.uint32), k
+        assert lib.orc_hit_bbox(*args) == g["b_hit"][k], k
+
+
+def test_materials(rt, O, lib):
+    g = np.load(os.path.join(G, "materials.npz"))
+    sc = O.orc_scatter()
+    kinds = set()
+    for k in range(len(g["t"])):
+        st = C.c_uint32(int(g["st_in"][k]))
+        m = g["mats"][k]
+        lib.orc_material_scatter(float(g["t"][k]), f3(g["normal"][k]), int(g["inside"][k]), f3(g["wo"][k]),
+                                 C.byref(rt.material.from_buffer_copy(m.tobytes())), f3(m["color"]), C.byref(st), C.byref(sc))
+        assert st.value == g["st_out"][k], k
+        assert (sc.specular | (sc.refracted << 1)) == g["flags"][k]
+        assert np.array_equal(_bits(np.array(sc.wi[:])), _bits(g["wi"][k])), k
+        assert np.array_equal(_bits(np.array(sc.throughput[:])), _bits(g["throughput"][k])), k
+        assert np.float32(sc.t) == g["t_out"][k]
+        kinds.add((int(m["type"]), int(g["flags"][k])))
+    assert {(0, 0), (1, 1), (2, 1), (2, 3)} <= kinds
+    out = (C.c_float * 3)()
+    for k in range(len(g["cos"])):
+        assert np.float32(lib.orc_schlick(float(g["cos"][k]), float(g["idx"][k]))) == g["schlick"][k]
+        lib.orc_reflect(f3(g["wo"][k]), f3(g["normal"][k]), out)
+        assert np.array_equal(_bits(np.array(out[:])), _bits(g["reflect"][k]))
+        lib.orc_refract(f3(g["wo"][k]), f3(g["normal"][k]), float(g["idx"][k]), out)
+        assert np.array_equal(_bits(np.array(out[:])), _bits(g["refract"][k]))
+    got = np.array([lib.orc_linear_to_srgb(float(x)) for x in g["srgb_in"]], np.uint32)
+    assert np.array_equal(got, g["srgb"])
+    # the product's sRGB (librt_host.so) as well
+    assert np.array_equal(np.array([rt.load_host().rtLinearToSRGB(float(x)) for x in g["srgb_in"]], np.uint32), g["srgb"])
+
+
+@pytest.mark.parametrize("name,nx,ny,ns,kw", [("c1_400x200x1", 400, 200, 1, {}), ("c1_200x100x4_rr", 200, 100, 4, {"rr": 1}),
+                                              ("rs_300x200x2", 300, 200, 2, {}), ("rs_96x64x8_counter", 96, 64, 8, {"rng": 1})])
+def test_frames(rt, O, name, nx, ny, ns, kw):
+    g = np.load(os.path.join(G, "frames.npz"))
+    sp, mt, cam = rt.scene_three_spheres(nx, ny) if name.startswith("c1") else rt.scene_random_spheres(nx, ny)
+    opt = O.default_options(True)
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    fb, cnt = O.render(O.sphere_scene(sp, mt), cam, opt, nx, ny, ns, 50, counters=True)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(fb.tobytes()).digest(), np.uint8), g[name + "_sha256"])
+    assert np.array_equal(_bits(fb[ny // 2 - 16:ny // 2 + 16, nx // 2 - 24:nx // 2 + 24]), _bits(g[name + "_crop"]))
+    assert np.array_equal(_bits(fb[::9, ::7]), _bits(g[name + "_strided"]))
+    assert [cnt.samples, cnt.rays, cnt.prim_tests, cnt.hits] == list(g[name + "_counts"])
+
+
+def test_benchmark_scene_is_the_fixture(rt):
+    """The 488-sphere scene + its 1200x800 camera produced by librt_host.so equal the committed fixture."""
+    g = np.load(os.path.join(G, "frames.npz"))
+    sp, mt, cam = rt.scene_random_spheres(1200, 800)
+    assert len(sp) == 488
+    assert sp.tobytes() == g["rs_scene_spheres"].tobytes() and mt.tobytes() == g["rs_scene_materials"].tobytes()
+    assert bytes(cam) == g["rs_scene_camera_1200x800"].tobytes()
+    # composition
+    assert (mt["type"] == rt.RT_DIFFUSE).sum() + (mt["type"] == rt.RT_METAL).sum() + (mt["type"] == rt.RT_GLASS).sum() == 488
+    assert tuple(sp[0]["center"]) == (0.0, -1000.0, -1.0) and sp[0]["radius"] == 1000.0
+    assert mt[-1]["type"] == rt.RT_METAL and mt[-2]["type"] == rt.RT_DIFFUSE and mt[-3]["type"] == rt.RT_GLASS
