@@ -15,7 +15,8 @@ OBJ      := build/obj
 
 KERNEL_HDRS := $(CSRC)/rt_device.h $(CSRC)/rt_params.h include/rt_types.h
 
-all: $(PKG)/librt_mi355x.so $(PKG)/librt_host.so oracle
+all: $(PKG)/librt_mi355x.so $(PKG)/librt_host.so
+	$(MAKE) -C oracle
 
 $(OBJ):
 	@mkdir -p $(OBJ)
@@ -44,7 +45,7 @@ $(PKG)/librt_mi355x.so: $(RT_OBJS)
 $(PKG)/librt_host.so: $(HOST)/rt_scenes.cpp $(HOST)/rt_bvh.cpp $(HOST)/rt_harness.cpp include/rt_host.h include/rt_types.h
 	$(CXX) -O2 -ffp-contract=off -std=c++14 -Wall -fPIC -shared $(HOST)/rt_scenes.cpp $(HOST)/rt_bvh.cpp $(HOST)/rt_harness.cpp -o $@
 
-oracle:
+oracle: $(PKG)/librt_mi355x.so $(PKG)/librt_host.so
 	$(MAKE) -C oracle
 
 clean:

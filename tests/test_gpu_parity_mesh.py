@@ -52,3 +52,26 @@ def test_mesh_nee_rr_within_tolerance(rt, O, stair):
     rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
     assert rel.mean() >= 0.999, rel.mean()
     assert abs(int(st.rays) - int(cnt.rays)) <= 0.001 * cnt.rays
+
+
+def test_drop_in_link_against_reference_headers(rt, O, stair, tmp_path):
+    """oracle/_ref/dropin_main was compiled against the REFERENCE'S kernels.h / helper_structs.h (its C++ classes,
+    by-value kernel_scene + camera arguments) and linked to our librt_mi355x.so: the three extern "C" symbols of
+    kernels.h:6-8 must bind and produce the same framebuffer as the Python ctypes path and the oracle."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "dropin_main")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_main was not built (needs /root/reference at build time)")
+    nx, ny, ns, depth = 64, 80, 2, 12
+    out = str(tmp_path / "fb.raw")
+    r = subprocess.run([exe, str(nx), str(ny), str(ns), str(depth), out], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    got = np.fromfile(out, np.float32).reshape(ny, nx, 3)
+    hm, mats = stair
+    cam = rt.staircase_camera(nx, ny)
+    via_python, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, depth)          # mesh defaults: NEE on, RR on
+    assert np.array_equal(_bits(got), _bits(via_python))
+    ref, _ = O.render(O.mesh_scene(hm, mats), cam, O.default_options(False), nx, ny, ns, depth)
+    rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
+    assert rel.mean() >= 0.999
