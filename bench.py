@@ -118,7 +118,9 @@ def main():
     # one counted run (untimed): rays per frame for the algorithmic flop count
     rt.setRenderOptions(opt, counters=1)
     step()
-    rays_local = rt.getRenderStats().rays
+    _st = rt.getRenderStats()
+    rays_local = _st.rays
+    exec_tests_local = _st.exec_tests
     rt.setRenderOptions(opt, counters=0)
     for _ in range(args.warmup):
         step()
@@ -162,6 +164,7 @@ def main():
                        "fp_mode": args.fp, "kernel_variant": args.variant},
             "frame_ms_kernel": kern_ms_max,
             "rays_per_sample": rays_total / total_samples,
+            "executed_sphere_tests_per_ray_rank0": (exec_tests_local / rays_local) if rays_local else None,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                          "kernel": "k_render_spheres", "kernel_ms_avg": kern_ms_max,

@@ -95,7 +95,7 @@ class render_options(C.Structure):
 class render_stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("samples", C.c_int64),
                 ("num_launches", C.c_int32), ("vgprs", C.c_int32), ("rays", C.c_uint64),
-                ("prim_tests", C.c_uint64), ("node_visits", C.c_uint64)]
+                ("prim_tests", C.c_uint64), ("node_visits", C.c_uint64), ("exec_tests", C.c_uint64)]
 
 
 _SIZES = {vec3: 12, camera: 88, sphere: 16, plane: 24, bbox: 24, triangle: 64, bvh_node: 24, material: 24,

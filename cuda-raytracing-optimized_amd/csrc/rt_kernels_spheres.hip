@@ -21,6 +21,11 @@
 //     Because a non-candidate returns FLT_MAX in the reference and never updates `closest`, and
 //     candidates are visited in increasing index with the same strict `<`, the result is
 //     bit-identical to the reference's linear scan;
+//   * sphere-group culling + pair compaction (scan_pairs): the host sorts the small spheres along a Morton curve
+//     into groups of 16 with an inflated AABB each; a ray only visits the groups whose box it enters before its
+//     current closest hit, and the (ray, group) pairs of a wave are compacted so that all 64 lanes always work.
+//     A skipped sphere could only have produced t > closest (rejected by the reference) or FLT_MAX, so the result
+//     is unchanged; the explicit (t, original index) tie rule keeps the reference's first-index-wins order;
 //   * framebuffer stores go through an LDS transpose so a wave writes row-contiguous dwords.
 #include "rt_device.h"
 #include "rt_params.h"
@@ -41,14 +46,17 @@ namespace {
 
 constexpr int kWavesPerWg = 4;              // 4 waves side by side: a 32 x 8 pixel tile per workgroup
 constexpr int kThreads = 64 * kWavesPerWg;
+constexpr int kPassGroups = 16;                                  // groups per pair-list pass: at most 64 x 16 pairs
+constexpr int kWaveScratch = 64 * 32 + 64 * 8 + 64 * kPassGroups * 2;     // per wave: ray table, best-hit keys, (lane, group) pair list
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     const int stripe = lr / pt.stripe_rows;
     return (stripe * pt.world + pt.rank) * pt.stripe_rows + (lr - stripe * pt.stripe_rows);
 }
 
-// sphereHit, intersections.h:85-104, on a pre-normalised direction `dn` with a = dot(dn,dn) hoisted
-// (same bits every call) and r2 = radius*radius precomputed (same bits).
+// sphereHit, intersections.h:85-104, on a pre-normalised direction `dn` with a = dot(dn,dn) hoisted (same bits every
+// call) and r2 = radius*radius precomputed (same bits).  `t_max` is INCLUSIVE here: the caller applies the reference's
+// strict `t < closest` itself, extended by the first-index-wins tie rule (see accept()).
 __device__ __forceinline__ float sphere_hit_exact(float4 s, f3 org, f3 dn, float a, float t_min, float t_max) {
     const f3 oc = org - F3(s.x, s.y, s.z);
     const float b = dot(oc, dn);
@@ -57,36 +65,57 @@ __device__ __forceinline__ float sphere_hit_exact(float4 s, f3 org, f3 dn, float
     if (discriminant > 0) {
         const float sq = rt_sqrt(discriminant);
         float temp = (-b - sq) / a;
-        if (temp < t_max && temp > t_min) return temp;
+        if (temp <= t_max && temp > t_min) return temp;
         temp = (-b + sq) / a;
-        if (temp < t_max && temp > t_min) return temp;
+        if (temp <= t_max && temp > t_min) return temp;
     }
     return FLT_MAX;
 }
 
+struct Hit { float closest; int sid; int orig; };    // sid = slot in the (re-ordered) scene arrays, orig = caller's index
+
+// The reference scans spheres in the caller's index order with a strict `t < closest`, i.e. it returns the
+// lexicographic minimum of (t_k, k).  We scan in a different (spatially sorted) order, so the tie is explicit.
+__device__ __forceinline__ void accept(Hit& h, float t, int slot, int orig) {
+    if (t < h.closest || (t == h.closest && orig < h.orig)) { h.closest = t; h.sid = slot; h.orig = orig; }
+}
+
 // LDS image of the scene, staged once per workgroup (README.md:93-103 used __constant__).
+__device__ __forceinline__ int sidx(int slot) { return slot + (slot >> 4); }
+
 struct SceneLds {
-    const float4* sph;      // n_padded x (cx, cy, cz, r*r)
-    const float4* mat;      // n x (r, g, b, param)
-    const int*    typ;      // n
+    const float4* sph;      // (cx, cy, cz, r*r) of slot k at index sidx(k) = k + k/16: 17 float4 per group of 16, so that
+                            // lanes reading DIFFERENT groups in one ds_read_b128 fall on different banks (pair scan)
+    const float4* grp;      // 2 x n_groups: inflated AABB (lo, hi) of each group of 16 slots
+    const float4* mat;      // n_padded x (r, g, b, param)
+    const int*    typ;      // n_padded
+    const int*    orig;     // n_padded: the caller's sphere index of each slot (INT_MAX for pad slots)
+    const int*    slot_of;  // n: slot of the caller's sphere index
+    unsigned char* scratch; // kWavesPerWg x kWaveScratch bytes of per-wave work space (pair scan)
 };
 
 __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigned char* smem, float** after) {
     float4* s_sph = reinterpret_cast<float4*>(smem);
-    float4* s_mat = s_sph + P.n_padded;
-    int*    s_typ = reinterpret_cast<int*>(s_mat + P.n);
+    float4* s_grp = s_sph + P.n_padded + P.n_groups;
+    float4* s_mat = s_grp + 2 * P.n_groups;
+    int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
+    int*    s_org = s_typ + P.n_padded;
     for (int k = threadIdx.x; k < P.n_padded; k += kThreads) {
         float4 s = P.spheres[k];
         s.w = s.w * s.w;                                             // intersections.h:89 radius*radius
-        s_sph[k] = s;
-    }
-    for (int k = threadIdx.x; k < P.n; k += kThreads) {
+        s_sph[sidx(k)] = s;
         s_mat[k] = P.mat_color[k];
         s_typ[k] = P.mat_type[k];
+        s_org[k] = P.orig[k];
     }
-    *after = reinterpret_cast<float*>(s_typ + ((P.n + 3) & ~3));
+    int*    s_sof = s_org + P.n_padded;
+    for (int k = threadIdx.x; k < 2 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
+    for (int k = threadIdx.x; k < P.n; k += kThreads) s_sof[k] = P.slot_of[k];
+    float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
+    *after = s_fb;
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(s_fb + kThreads * 3);
     __syncthreads();
-    return { s_sph, s_mat, s_typ };
+    return { s_sph, s_grp, s_mat, s_typ, s_org, s_sof, scratch };
 }
 
 // Per-lane path state (path, helper_structs.h:48-71, minus what sphere scenes never use).
@@ -124,45 +153,51 @@ __device__ __forceinline__ void start_pixel(const RtSphereParams& P, Lane& L, in
     start_sample(P, L);
 }
 
-struct Hit { float closest; int sid; };
-
-// ---- closest hit, LANE-PARALLEL form: every lane scans all spheres for its own ray --------------------------------
-// `dn` is the renormalised direction (hit() rebuilds the ray: kernels.cu:326, ray.h:9), a = dot(dn,dn).
-__device__ __forceinline__ Hit scan_lane_parallel(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a) {
-    const float t_min = P.t_min;
-    const int ngroups = P.n_padded >> 5;
-    Hit h = { FLT_MAX, -1 };
-    for (int g = 0; g < ngroups; g++) {
-        const float4* sp = S.sph + (g << 5);
-        uint32_t mask = 0;
+// One group of 16 consecutive slots, scanned by every live lane for its own ray (sphere data broadcast from LDS).
+// Phase 1: 16 VALU ops per sphere in exactly the reference's rounding order + one v_alignbit that shifts the sign of
+// -(discriminant) into a mask.  Phase 2: the literal sphereHit tail for the set bits only.
+__device__ __forceinline__ void scan_group_broadcast(const RtSphereParams& P, const SceneLds& S, int g, f3 org, f3 dn, float a, Hit& h) {
+    const int base = g << 4;
+    const float4* sp = S.sph + sidx(base);
+    uint32_t mask = 0;
 #pragma unroll
-        for (int kk = 0; kk < 32; kk++) {
-            const float4 sph = sp[kk];                               // wave-uniform address: LDS broadcast
-            const float ocx = org.x - sph.x;
-            const float ocy = org.y - sph.y;
-            const float ocz = org.z - sph.z;
-            const float b = ocx * dn.x + ocy * dn.y + ocz * dn.z;
-            const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
-            const float nd = a * c - b * b;                          // == -(b*b - a*c) bit for bit
-            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);   // mask = mask<<1 | sign(nd)
-        }
-        while (mask) {                                               // candidates, lowest sphere index first
-            const int lz = __clz((int)mask);
-            mask &= ~(0x80000000u >> lz);
-            const int k = (g << 5) + lz;
-            const float t = sphere_hit_exact(S.sph[k], org, dn, a, t_min, h.closest);
-            if (k < P.n && t < h.closest) { h.closest = t; h.sid = k; }
-        }
+    for (int kk = 0; kk < 16; kk++) {
+        const float4 sph = sp[kk];                                   // wave-uniform address: LDS broadcast
+        const float ocx = org.x - sph.x;
+        const float ocy = org.y - sph.y;
+        const float ocz = org.z - sph.z;
+        const float b = ocx * dn.x + ocy * dn.y + ocz * dn.z;
+        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
+        const float nd = a * c - b * b;                              // == -(b*b - a*c) bit for bit
+        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);   // mask = mask<<1 | sign(nd)
+    }
+    mask <<= 16;                                                     // slot `base` at bit 31
+    while (mask) {                                                   // candidates
+        const int lz = __clz((int)mask);
+        mask &= ~(0x80000000u >> lz);
+        const int k = base + lz;
+        const float t = sphere_hit_exact(S.sph[sidx(k)], org, dn, a, P.t_min, h.closest);
+        const int o = S.orig[k];
+        if (o != 0x7fffffff && t < FLT_MAX) accept(h, t, k, o);
+    }
+}
+
+// ---- closest hit, LANE-PARALLEL brute force (kept for A/B): every lane scans every group ---------------------------
+// `dn` is the renormalised direction (hit() rebuilds the ray: kernels.cu:326, ray.h:9), a = dot(dn,dn).
+__device__ __forceinline__ Hit scan_lane_parallel(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, uint32_t& groups_done) {
+    Hit h = { FLT_MAX, -1, 0x7fffffff };
+    for (int g = 0; g < P.n_groups; g++) {
+        groups_done++;
+        scan_group_broadcast(P, S, g, org, dn, a, h);
     }
     return h;
 }
 
-// ---- closest hit, WAVE-COOPERATIVE form: the 64 lanes share ONE ray (that of lane q) ---------------------------------
-// Lane l tests spheres l, l+64, l+128, ...; the per-lane results are merged with the reference's tie rule.
-// Why this is still the reference's answer: sphereHit's result for sphere k does not depend on the running
-// `closest` except for acceptance (the far root is never below the near root), so the linear scan computes the
-// lexicographic minimum of (t_k, k) over all spheres — which can be evaluated in any order.
-// Must be called by all 64 lanes of the wave in uniform control flow; q is wave-uniform.
+// ---- closest hit, WAVE-COOPERATIVE brute force (kept for A/B): the 64 lanes share ONE ray (that of lane q) ----------
+// Lane l tests slot 64*r + l in round r.  The per-lane results are merged with the reference's tie rule.  Why this is
+// still the reference's answer: sphereHit's result for sphere k does not depend on the running `closest` except for
+// acceptance (the far root is never below the near root), so the linear scan computes the lexicographic minimum of
+// (t_k, k) over all spheres — which can be evaluated in any order.  WAVE-LEVEL; q is wave-uniform.
 __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const SceneLds& S, int q, f3 org, f3 dn, float a) {
     const int lane = threadIdx.x & 63;
     const f3 O = F3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.x), q)),
@@ -172,46 +207,242 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.y), q)),
                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.z), q)));
     const float A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), q));
-    const float t_min = P.t_min;
     const int rounds = P.n_padded >> 6;
-    float bt = FLT_MAX;
-    int bk = 0x7fffffff;
-    for (int r0 = 0; r0 < rounds; r0 += 32) {
-        const int rc = min(32, rounds - r0);
-        uint32_t cm = 0;
-        for (int r = 0; r < rc; r++) {
-            const float4 sph = S.sph[((r0 + r) << 6) + lane];
-            const float ocx = O.x - sph.x;
-            const float ocy = O.y - sph.y;
-            const float ocz = O.z - sph.z;
-            const float b = ocx * D.x + ocy * D.y + ocz * D.z;
-            const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
-            const float nd = A * c - b * b;
-            cm = __builtin_amdgcn_alignbit(cm, __float_as_uint(nd), 31);
-        }
-        cm <<= (32 - rc);                                            // round r0 at bit 31
-        while (cm) {
-            const int lz = __clz((int)cm);
-            cm &= ~(0x80000000u >> lz);
-            const int k = ((r0 + lz) << 6) + lane;
-            const float t = sphere_hit_exact(S.sph[k], O, D, A, t_min, bt);
-            if (k < P.n && t < bt) { bt = t; bk = k; }
+    Hit h = { FLT_MAX, -1, 0x7fffffff };
+    for (int r = 0; r < rounds; r++) {
+        const int k = (r << 6) + lane;
+        const float4 sph = S.sph[sidx(k)];
+        const f3 oc = O - F3(sph.x, sph.y, sph.z);
+        const float b = oc.x * D.x + oc.y * D.y + oc.z * D.z;
+        const float c = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - sph.w;
+        const float nd = A * c - b * b;
+        if (nd < 0.0f) {
+            const float t = sphere_hit_exact(sph, O, D, A, P.t_min, h.closest);
+            const int o = S.orig[k];
+            if (o != 0x7fffffff && t < FLT_MAX) accept(h, t, k, o);
         }
     }
-    // merge: lexicographic minimum of (t, k) over the lanes that found something.  t > t_min >= 0, so the
+    // merge: lexicographic minimum of (t, orig) over the lanes that found something.  t > t_min >= 0, so the
     // IEEE bit patterns order like the values and the merge runs on the scalar unit.
-    unsigned long long found = __ballot(bt < FLT_MAX);
+    unsigned long long found = __ballot(h.closest < FLT_MAX);
     uint32_t st = __float_as_uint(FLT_MAX);
-    int sk = -1;
+    int sk = -1, so = 0x7fffffff;
     while (found) {
         const int b = __builtin_ctzll(found);
         found &= found - 1;
-        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(bt), b);
-        const int kb = __builtin_amdgcn_readlane(bk, b);
-        if (tb < st || (tb == st && kb < sk)) { st = tb; sk = kb; }
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(h.closest), b);
+        const int ob = __builtin_amdgcn_readlane(h.orig, b);
+        if (tb < st || (tb == st && ob < so)) { st = tb; so = ob; sk = __builtin_amdgcn_readlane(h.sid, b); }
     }
-    Hit h = { __uint_as_float(st), sk };
-    return h;
+    Hit out = { __uint_as_float(st), sk, so };
+    return out;
+}
+
+// Which small-sphere groups can still give this ray a closer hit?  Slab test of the ray against the group's inflated
+// AABB; bit g = "the ray enters the box at a distance not beyond its current closest hit".  Conservative by
+// construction: the box is inflated on the host by far more than the rounding error of this test, the entry distance is
+// shrunk by 1e-5 relative + 1e-4 absolute before it is compared, and any NaN (0 * inf on a slab plane) compares false,
+// i.e. keeps the group.  A skipped group could only have produced hits with t > closest, which the reference rejects.
+// Handles up to 32 groups per call (groups g0 .. g0+ng-1).
+__device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, f3 org, f3 inv, float closest, bool cull) {
+    if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
+    uint32_t need = 0;
+    for (int g = 0; g < ng; g++) {
+        const float4 lo = S.grp[2 * (g0 + g)], hi = S.grp[2 * (g0 + g) + 1];      // wave-uniform address: LDS broadcast
+        const float x0 = (lo.x - org.x) * inv.x, x1 = (hi.x - org.x) * inv.x;
+        const float y0 = (lo.y - org.y) * inv.y, y1 = (hi.y - org.y) * inv.y;
+        const float z0 = (lo.z - org.z) * inv.z, z1 = (hi.z - org.z) * inv.z;
+        const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const bool skip = (t_in > t_out) || (t_out < 0.0f) || (t_in * 0.99999f - 1.0e-4f > closest);
+        need |= (skip ? 0u : 1u) << g;
+    }
+    return need;
+}
+
+// ---- closest hit, PAIR-COMPACTED form (default) ---------------------------------------------------------------------
+// 1. Every live lane scans the BIG spheres (ground, unit spheres) for its own ray: a first `closest`.
+// 2. Every live lane finds the small-sphere groups its ray can still reach before that hit (a few of the ~31).
+// 3. The (ray, group) PAIRS of the whole wave are written densely into an LDS list (wave64 prefix sum of the per-lane
+//    pair counts) and processed 64 at a time: pair-lane j fetches ray + group of pair j, runs the 16 sphere tests,
+//    resolves its candidates exactly and folds its best (t, original index) into the owner's slot with one 64-bit LDS
+//    atomic min (t > 0, so the IEEE bits order like the values: the minimum of (t_bits << 32 | orig) IS the
+//    reference's first-index-wins closest hit).
+// The work a wave does is proportional to the pairs that exist, not to 64 x (union of groups): incoherent waves do not
+// pay for each other's groups, and a wave with few live rays uses all 64 lanes on them.  WAVE-LEVEL: all 64 lanes call it.
+__device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, bool has_ray, bool cull,
+                                          uint32_t& groups_done) {
+    const int lane = threadIdx.x & 63;
+    unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
+    float4* w_ray = reinterpret_cast<float4*>(W);                               // 64 x 2 float4
+    unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
+    unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);
+    const float t_min = P.t_min;
+
+    Hit hb = { FLT_MAX, -1, 0x7fffffff };
+    if (has_ray)
+        for (int g = 0; g < P.n_big_groups; g++) { groups_done++; scan_group_broadcast(P, S, g, org, dn, a, hb); }
+
+    w_ray[2 * lane] = make_float4(org.x, org.y, org.z, a);
+    w_ray[2 * lane + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
+    w_best[lane] = (hb.sid >= 0) ? (((unsigned long long)__float_as_uint(hb.closest) << 32) | (unsigned long long)(uint32_t)hb.orig) : ~0ull;
+    const f3 inv = F3(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+
+    for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
+        const int ng = min(kPassGroups, P.n_groups - g0);
+        const uint32_t need = has_ray ? group_needs(S, g0, ng, org, inv, hb.closest, cull) : 0u;
+        // exclusive prefix sum of the pair counts over the wave
+        const int cnt = __popc(need);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int at = incl - cnt;
+        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 8) | __builtin_ctz(m));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        for (int base = 0; base < total; base += 64) {
+            const int j = base + lane;
+            if (j < total) {
+                const unsigned pr = w_pair[j];
+                const int owner = (int)(pr >> 8);
+                const int slot0 = (g0 + (int)(pr & 0xFFu)) << 4;
+                const int sbase = sidx(slot0);
+                const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
+                const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
+                const float A = ro.w;
+                groups_done++;
+                uint32_t mask = 0;
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) {
+                    const float4 sph = S.sph[sbase + kk];
+                    const float ocx = O.x - sph.x;
+                    const float ocy = O.y - sph.y;
+                    const float ocz = O.z - sph.z;
+                    const float b = ocx * D.x + ocy * D.y + ocz * D.z;
+                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
+                    const float nd = A * c - b * b;                  // == -(b*b - a*c) bit for bit
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);
+                }
+                mask <<= 16;                                         // slot0 at bit 31
+                Hit h = { FLT_MAX, -1, 0x7fffffff };
+                while (mask) {
+                    const int lz = __clz((int)mask);
+                    mask &= ~(0x80000000u >> lz);
+                    const int k = slot0 + lz;
+                    const float t = sphere_hit_exact(S.sph[sidx(k)], O, D, A, t_min, h.closest);
+                    const int o = S.orig[k];
+                    if (o != 0x7fffffff && t < FLT_MAX) accept(h, t, k, o);
+                }
+                if (h.sid >= 0)
+                    atomicMin(&w_best[owner], ((unsigned long long)__float_as_uint(h.closest) << 32) | (unsigned long long)(uint32_t)h.orig);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned long long key = w_best[lane];
+    Hit out = { FLT_MAX, -1, 0x7fffffff };
+    if (key != ~0ull) {
+        out.closest = __uint_as_float((uint32_t)(key >> 32));
+        out.orig = (int)(uint32_t)key;
+        out.sid = S.slot_of[out.orig];
+    }
+    return out;
+}
+
+// ---- closest hit, SPARSE form: at most kSparseRays live rays in the wave ----------------------------------------------
+// The tail of the frame belongs to a handful of pixels whose paths are trapped inside glass for up to maxDepth bounces
+// (thousands of rays, strictly sequential because of the per-pixel RNG stream).  For them the latency of ONE ray is what
+// counts, so the wave spends all 64 lanes on each live ray in turn: 16 lanes per group, 4 groups per step; the group
+// boxes are tested one group per lane.  Same exact tests, same (t, original index) merge as scan_pairs.  WAVE-LEVEL.
+constexpr int kSparseRays = 4;
+
+__device__ __forceinline__ void sparse_test_slot(const RtSphereParams& P, const SceneLds& S, int slot, f3 O, f3 D, float A,
+                                                 unsigned long long* best) {
+    const float4 sph = S.sph[sidx(slot)];
+    const f3 oc = O - F3(sph.x, sph.y, sph.z);
+    const float b = oc.x * D.x + oc.y * D.y + oc.z * D.z;
+    const float c = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - sph.w;
+    const float nd = A * c - b * b;
+    if (nd < 0.0f) {
+        const float t = sphere_hit_exact(sph, O, D, A, P.t_min, FLT_MAX);
+        const int o = S.orig[slot];
+        if (o != 0x7fffffff && t < FLT_MAX)
+            atomicMin(best, ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)o);
+    }
+}
+
+__device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, unsigned long long live,
+                                           bool cull) {
+    const int lane = threadIdx.x & 63;
+    unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
+    unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
+    w_best[lane] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned long long m = live; m; m &= m - 1) {
+        const int q = __builtin_ctzll(m);                            // wave-uniform
+        const f3 O = F3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.x), q)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.y), q)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.z), q)));
+        const f3 D = F3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.x), q)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.y), q)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.z), q)));
+        const float A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), q));
+        // (a) big spheres: one slot per lane
+        for (int s0 = 0; s0 < (P.n_big_groups << 4); s0 += 64)
+            if (s0 + lane < (P.n_big_groups << 4)) sparse_test_slot(P, S, s0 + lane, O, D, A, &w_best[q]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float closest = __uint_as_float((uint32_t)(w_best[q] >> 32));      // FLT_MAX-or-larger bit pattern if none: keeps everything
+        const f3 inv = F3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+        // (b) one group box per lane, (c) 4 reachable groups per step, 16 lanes each
+        for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += 64) {
+            const int g = g0 + lane;
+            bool reach = false;
+            if (g < P.n_groups) {
+                if (!cull) {
+                    reach = true;
+                } else {
+                    const float4 lo = S.grp[2 * g], hi = S.grp[2 * g + 1];
+                    const float x0 = (lo.x - O.x) * inv.x, x1 = (hi.x - O.x) * inv.x;
+                    const float y0 = (lo.y - O.y) * inv.y, y1 = (hi.y - O.y) * inv.y;
+                    const float z0 = (lo.z - O.z) * inv.z, z1 = (hi.z - O.z) * inv.z;
+                    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    reach = !((t_in > t_out) || (t_out < 0.0f) || (t_in * 0.99999f - 1.0e-4f > closest));
+                }
+            }
+            unsigned long long gm = __ballot(reach);
+            while (gm) {
+                int gsel = -1;                                       // this lane's group: the (lane>>4)-th of the next 4 set bits
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if (gm) {
+                        const int gb = __builtin_ctzll(gm);
+                        gm &= gm - 1;
+                        if ((lane >> 4) == w) gsel = g0 + gb;
+                    }
+                }
+                if (gsel >= 0) sparse_test_slot(P, S, (gsel << 4) + (lane & 15), O, D, A, &w_best[q]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long key = w_best[lane];
+    Hit out = { FLT_MAX, -1, 0x7fffffff };
+    if (((live >> lane) & 1ull) && key != ~0ull) {
+        out.closest = __uint_as_float((uint32_t)(key >> 32));
+        out.orig = (int)(uint32_t)key;
+        out.sid = S.slot_of[out.orig];
+    }
+    return out;
 }
 
 // ---- shading of one hit / miss: the rest of color()'s loop body (kernels.cu:415-531) -------------------------------
@@ -221,8 +452,8 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
         L.pcolor = L.pcolor + L.atten * sky_color(P.sky, L.dir);     // kernels.cu:419-425
         return true;
     }
-    const float4 sc4 = S.sph[h.sid];
-    const float radius = P.spheres[h.sid].w;
+    const float4 sc4 = S.sph[sidx(h.sid)];
+    const float radius = P.spheres[h.sid].w;                         // slot-indexed, like every scene array on the device
     const f3 hp = L.org + h.closest * dn;                            // ray.h:12 point_at_parameter
     f3 normal = (hp - F3(sc4.x, sc4.y, sc4.z)) / radius;             // intersections.h:95
     if (dot(dn, normal) > 0.0f) normal = -normal;                    // kernels.cu:354-355
@@ -252,14 +483,19 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // lanes must call it together.  With many live lanes each lane scans the sphere list for its own ray; with few
 // (the tail of a tile / of the frame, where a handful of glass-trapped pixels need thousands of rays each) the
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
-__device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below) {
+template <bool LEGACY>
+__device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
+                                           uint32_t& groups_done) {
     // ---- hit(), kernels.cu:325-360: the ray is rebuilt from the path, which renormalises the direction
     const f3 dn = unit(L.dir);
     const float a = dot(dn, dn);
-    Hit h = { FLT_MAX, -1 };
+    Hit h = { FLT_MAX, -1, 0x7fffffff };
     const unsigned long long live = __ballot(has_ray);
-    if (__popcll(live) >= coop_below) {
-        if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a);
+    if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
+        if (__popcll(live) <= kSparseRays && coop_below == -1) h = scan_sparse(P, S, L.org, dn, a, live, cull);
+        else h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done);
+    } else if (__popcll(live) >= coop_below) {
+        if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
     } else {
         unsigned long long m = live;
         const int lane = threadIdx.x & 63;
@@ -276,7 +512,8 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
 }
 
 // ---- variant 1: one 8x8 pixel tile per wave, the lane keeps its pixel for the whole kernel ------------------------
-__global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSphereParams P, int coop_below) {
+template <bool LEGACY>
+__global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSphereParams P, int coop_below, int cull) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* s_fb;
     const SceneLds S = stage_scene(P, smem, &s_fb);                  // s_fb: kThreads x 3 floats
@@ -292,13 +529,13 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
     Lane L;
     L.col = F3(0, 0, 0);
     L.org = F3(0, 0, 0); L.dir = F3(0, 0, 1);
-    uint32_t nrays = 0;
+    uint32_t nrays = 0, groups_done = 0;
     bool active = valid && (P.ns > 0);
     if (active) start_pixel(P, L, i, global_row(P.part, lr));
 
     while (__ballot(active) != 0ull) {                               // wave-uniform loop: idle lanes stay to help
         if (active) nrays++;
-        const bool done = trace_rays(P, S, L, active, coop_below);
+        const bool done = trace_rays<LEGACY>(P, S, L, active, coop_below, cull != 0, groups_done);
         if (active && done) {
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
@@ -327,6 +564,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
+        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 16ull);     // lane-parallel phase-1 tests executed
     }
 }
 
@@ -356,12 +594,12 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
         const float u = ((float)i + 0.5f) / (float)P.nx, v = ((float)j + 0.5f) / (float)P.ny;
         const f3 org = ld3(P.cam.origin);
         const f3 dn = unit(ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - org);
-        for (int k = 0; k < P.n; k++) {
-            const float4 sph = S.sph[k];
+        for (int k = 0; k < P.n_padded; k++) {
+            const float4 sph = S.sph[sidx(k)];
             const f3 oc = org - F3(sph.x, sph.y, sph.z);
             const float b = dot(oc, dn);
             const float c = dot(oc, oc) - sph.w;
-            hits = hits || ((b * b - c > 0.0f) && (b < 0.0f || c < 0.0f));
+            hits = hits || ((S.orig[k] != 0x7fffffff) && (b * b - c > 0.0f) && (b < 0.0f || c < 0.0f));
         }
     }
     const unsigned long long ma = __ballot(valid && hits), mb = __ballot(valid && !hits);
@@ -388,7 +626,9 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
 // therefore traces a ray in (almost) every iteration until the queue is empty; which lane renders which pixel is
 // irrelevant to the result because the seed is a function of the global pixel id only.
 
-__global__ void __launch_bounds__(kThreads) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified) {
+template <bool LEGACY>
+__global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
+                                                                   int cull) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
     const SceneLds S = stage_scene(P, smem, &unused);
@@ -414,7 +654,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_queue(const RtSpher
     L.col = F3(0, 0, 0);
     L.org = F3(0, 0, 0); L.dir = F3(0, 0, 1);
     int lr = 0;                         // local row of the lane's pixel (framebuffer row)
-    uint32_t nrays = 0;
+    uint32_t nrays = 0, groups_done = 0;
     bool have_pixel = false;            // lane owns an unfinished pixel
     bool exhausted = false;             // wave-uniform: the global queue is empty
     float* fbf = reinterpret_cast<float*>(P.fb);
@@ -465,7 +705,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_queue(const RtSpher
 
         // ---- one ray per live lane ----------------------------------------------------------------------------
         if (have_pixel) nrays++;
-        const bool done = trace_rays(P, S, L, have_pixel, coop_below);
+        const bool done = trace_rays<LEGACY>(P, S, L, have_pixel, coop_below, cull != 0, groups_done);
         if (have_pixel && done) {
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
@@ -483,6 +723,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_queue(const RtSpher
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
+        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 16ull);     // lane-parallel phase-1 tests executed
     }
     if (P.wave_dbg && (threadIdx.x & 63) == 0) {
         unsigned long long* w = P.wave_dbg + ((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 8;
@@ -496,7 +737,9 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_queue(const RtSpher
 }  // namespace
 
 static size_t lds_bytes(int n_padded, int n) {
-    return (size_t)n_padded * 16 + (size_t)n * 16 + (size_t)((n + 3) & ~3) * 4 + (size_t)kThreads * 3 * 4;
+    // spheres + group bounds + material colour + type + original index per slot, + fb staging of the tile kernel
+    return (size_t)(n_padded + n_padded / 16) * 16 + (size_t)(n_padded / 16) * 32 + (size_t)n_padded * 16 + (size_t)n_padded * 8 +
+           (size_t)((n + 3) & ~3) * 4 + (size_t)kThreads * 3 * 4 + (size_t)kWavesPerWg * kWaveScratch;
 }
 
 #if defined(RT_MODE_PARITY)
@@ -508,25 +751,32 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n, int threads) {
 
 // variant: bits 0..7   kernel: 0 = persistent waves + pixel queue (default), 1 = one tile per wave;
 //          bits 8..15  workgroups per CU of the persistent kernel (0 = default 4);
-//          bits 16..23 switch to the wave-cooperative scan when fewer than this many lanes of a wave have a ray
-//                      (0 = default 24; 1 = never cooperative, 65 = always cooperative);
+//          bits 16..23 0 = pair-compacted scan + sparse form (default); 255 = pair-compacted scan only.  Otherwise the earlier hybrid: lane-parallel scan, switching
+//                      to the wave-cooperative scan when fewer than this many lanes of a wave have a ray
+//                      (1 = never cooperative, 65 = always cooperative);
+//          bit  26     disable sphere-group culling (every group is scanned: the plain brute-force scan);
 //          bits 24..25 work order of the persistent kernel: 0 = classified (hit-something pixels scattered, sky
 //                      pixels last; needs the classify pre-pass), 1 = tile-major, 2 = scattered only.
 hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
     const size_t lds = lds_bytes(p.n_padded, p.n);
     const int kind = variant & 0xFF;
-    const void* kern = (kind == 1) ? reinterpret_cast<const void*>(k_render_spheres_tiles)
-                                   : reinterpret_cast<const void*>(k_render_spheres_queue);
+    const int cb_bits = (variant >> 16) & 0xFF;
+    const bool legacy = cb_bits != 0 && cb_bits != 255;
+    const void* kern = (kind == 1) ? (legacy ? reinterpret_cast<const void*>(k_render_spheres_tiles<true>) : reinterpret_cast<const void*>(k_render_spheres_tiles<false>))
+                                   : (legacy ? reinterpret_cast<const void*>(k_render_spheres_queue<true>) : reinterpret_cast<const void*>(k_render_spheres_queue<false>));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_spheres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    const int cull = ((variant >> 26) & 1) ? 0 : 1;
     int coop_below = (variant >> 16) & 0xFF;
-    if (coop_below == 0) coop_below = 24;
+    if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
+    if (coop_below == 255) coop_below = -2;    // pair-compacted scan only (A/B)
     if (kind == 1) {
         const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
-        hipLaunchKernelGGL(k_render_spheres_tiles, grid, dim3(kThreads), lds, stream, p, coop_below);
+        if (legacy) hipLaunchKernelGGL(k_render_spheres_tiles<true>, grid, dim3(kThreads), lds, stream, p, coop_below, cull);
+        else hipLaunchKernelGGL(k_render_spheres_tiles<false>, grid, dim3(kThreads), lds, stream, p, coop_below, cull);
         return hipGetLastError();
     }
     if (!p.queue) return hipErrorInvalidValue;
@@ -556,6 +806,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
-    hipLaunchKernelGGL(k_render_spheres_queue, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified);
+    if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull);
+    else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull);
     return hipGetLastError();
 }

@@ -23,16 +23,22 @@ struct RtCounters {             // device-side, optional
     unsigned long long prim_tests;
     unsigned long long node_visits;
     unsigned long long shadow_rays;
+    unsigned long long exec_tests;   // sphere tests actually executed per lane in the lane-parallel scan (after group culling)
 };
 
 struct RtSphereParams {
     rt_camera cam;
     int32_t nx, ny, ns, max_depth;
     int32_t n;                  // spheres
-    int32_t n_padded;           // multiple of 64 (pad entries can never be hit)
-    const float4* spheres;      // n_padded x (cx, cy, cz, radius)
-    const float4* mat_color;    // n x (r, g, b, param)
-    const int32_t* mat_type;    // n
+    int32_t n_padded;           // slots: multiple of 64; slots are grouped 16 by 16 (pad slots can never be hit)
+    int32_t n_groups;           // n_padded / 16
+    int32_t n_big_groups;       // groups [0, n_big_groups) hold the big spheres: always scanned
+    const float4* spheres;      // n_padded x (cx, cy, cz, radius), spatially sorted (see rt_renderer.hip build_sphere_groups)
+    const float4* groups;       // 2 x n_groups: inflated AABB (lo.xyz, hi.xyz) of each group
+    const float4* mat_color;    // n_padded x (r, g, b, param)
+    const int32_t* mat_type;    // n_padded
+    const int32_t* orig;        // n_padded: caller's sphere index of the slot, INT_MAX for pad slots
+    const int32_t* slot_of;     // n: slot of the caller's sphere index
     rt_vec3* fb;                // compact framebuffer: local_rows x nx
     RtPartition part;
     int32_t sky;

@@ -13,7 +13,9 @@
 //   * the kernel is timed with HIP events on the stream it is launched on (getRenderStats).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +49,9 @@ struct DeviceState {
     float4* d_spheres = nullptr;
     float4* d_mat_color = nullptr;
     int32_t* d_mat_type = nullptr;
+    float4* d_groups = nullptr;
+    int32_t* d_orig = nullptr;
+    int32_t* d_slot_of = nullptr;
     // mesh scene
     rt_triangle* d_tris = nullptr;
     float4* d_bvh = nullptr;
@@ -75,7 +80,10 @@ struct RenderContext {
     std::vector<float4> h_spheres;      // padded
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
-    int n_spheres = 0, n_padded = 0;
+    std::vector<float4> h_groups;       // two float4 per group of 16 slots: inflated AABB lo / hi
+    std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
+    std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
+    int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0;
     std::vector<rt_triangle> h_tris;
     std::vector<float4> h_bvh;          // numBvhNodes * 24 B viewed as float4 (padded)
     int num_bvh_nodes = 0;
@@ -113,7 +121,7 @@ void free_device(DeviceState& d) {
     HIP_CHECK(hipSetDevice(d.device));
     if (d.stream) HIP_CHECK(hipStreamSynchronize(d.stream));
     auto fr = [](void* p) { if (p) HIP_CHECK(hipFree(p)); };
-    fr(d.d_spheres); fr(d.d_mat_color); fr(d.d_mat_type);
+    fr(d.d_spheres); fr(d.d_mat_color); fr(d.d_mat_type); fr(d.d_groups); fr(d.d_orig); fr(d.d_slot_of);
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
@@ -164,6 +172,9 @@ void setup_devices() {
             d.d_spheres = upload(c.h_spheres);
             d.d_mat_color = upload(c.h_mat_color);
             d.d_mat_type = upload(c.h_mat_type);
+            d.d_groups = upload(c.h_groups);
+            d.d_orig = upload(c.h_orig);
+            d.d_slot_of = upload(c.h_slot_of);
         } else {
             d.d_tris = upload(c.h_tris);
             d.d_bvh = upload(c.h_bvh);
@@ -216,6 +227,100 @@ void common_init(const rt_camera& cam, rt_vec3** fb, int nx, int ny, int maxDept
     memset(&c.stats, 0, sizeof c.stats);
     setup_devices();
     c.initialised = true;
+}
+
+
+// Device layout of a sphere scene.  The spheres are re-ordered into SLOTS, 16 slots per group:
+//   * "big" spheres (radius > 4 x the median radius: the ground and the three unit spheres of the benchmark scene)
+//     come first; their groups are always scanned, by every lane, and give each ray a first `closest`;
+//   * "small" spheres are sorted along a 3D Morton curve so that consecutive slots are neighbours in space; each
+//     group of 16 gets an axis-aligned bounding box, inflated well beyond fp32 rounding (1 % + 1e-4 of the scene
+//     extent), which the kernel uses to skip the group for rays that cannot reach it before their current hit;
+//   * pad slots fill the last group of each class and the tail up to a multiple of 64 slots; they carry
+//     orig = INT_MAX and are never accepted.
+// Scanning in slot order instead of the caller's order cannot change the result: the kernel resolves equal-t ties
+// by the caller's index (h_orig), which is exactly the reference's first-index-wins rule.
+void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials, int n) {
+    RenderContext& c = g_ctx;
+    std::vector<float> radii(n);
+    for (int k = 0; k < n; k++) radii[k] = fabsf(spheres[k].radius);
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const float big_above = 4.0f * sorted[n / 2];
+    std::vector<int> small, big;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (int k = 0; k < n; k++) {
+        if (radii[k] > big_above || !std::isfinite(radii[k])) { big.push_back(k); continue; }
+        small.push_back(k);
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], (double)spheres[k].center.e[a]);
+            hi[a] = std::max(hi[a], (double)spheres[k].center.e[a]);
+        }
+    }
+    auto morton = [&](int k) {
+        uint32_t code = 0, q[3];
+        for (int a = 0; a < 3; a++) {
+            const double ext = hi[a] - lo[a];
+            q[a] = ext > 0 ? (uint32_t)std::min(1023.0, (spheres[k].center.e[a] - lo[a]) / ext * 1024.0) : 0u;
+        }
+        for (int b = 9; b >= 0; b--)
+            for (int a = 0; a < 3; a++) code = (code << 1) | ((q[a] >> b) & 1u);
+        return code;
+    };
+    std::vector<std::pair<uint32_t, int>> keyed;
+    for (int k : small) keyed.emplace_back(morton(k), k);
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<int> slots;                                     // slot -> caller index, -1 = pad
+    for (int k : big) slots.push_back(k);                       // big spheres first: groups [0, n_big_groups)
+    while (slots.size() % 16) slots.push_back(-1);
+    const int n_big_groups = (int)slots.size() / 16;
+    for (auto& kv : keyed) slots.push_back(kv.second);
+    while (slots.size() % 64) slots.push_back(-1);
+
+    double extent = 1.0;
+    for (int a = 0; a < 3; a++) if (hi[a] > lo[a]) extent = std::max(extent, hi[a] - lo[a]);
+    c.n_spheres = n;
+    c.n_padded = (int)slots.size();
+    c.n_groups = c.n_padded / 16;
+    c.n_big_groups = n_big_groups;
+    c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));      // pad: radius 0, far away
+    c.h_mat_color.assign(c.n_padded, make_float4(0, 0, 0, 0));
+    c.h_mat_type.assign(c.n_padded, RT_DIFFUSE);
+    c.h_orig.assign(c.n_padded, INT_MAX);
+    c.h_slot_of.assign(n, 0);
+    // bounds: 2 float4 per group = AABB lo / hi.  Empty group: lo > hi on every axis (never reachable).
+    c.h_groups.assign((size_t)c.n_groups * 2, make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f));
+    for (int g = 0; g < c.n_groups; g++) c.h_groups[2 * g + 1] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f);
+    for (int s = 0; s < c.n_padded; s++) {
+        const int k = slots[s];
+        if (k < 0) continue;
+        c.h_spheres[s] = make_float4(spheres[k].center.e[0], spheres[k].center.e[1], spheres[k].center.e[2], spheres[k].radius);
+        c.h_mat_color[s] = make_float4(materials[k].color.e[0], materials[k].color.e[1], materials[k].color.e[2], materials[k].param);
+        c.h_mat_type[s] = materials[k].type;
+        c.h_orig[s] = k;
+        c.h_slot_of[k] = s;
+    }
+    for (int g = n_big_groups; g < c.n_groups; g++) {
+        double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
+        int cnt = 0;
+        for (int s = g * 16; s < g * 16 + 16; s++) {
+            if (slots[s] < 0) continue;
+            cnt++;
+            for (int a = 0; a < 3; a++) {
+                blo[a] = std::min(blo[a], (double)spheres[slots[s]].center.e[a] - radii[slots[s]]);
+                bhi[a] = std::max(bhi[a], (double)spheres[slots[s]].center.e[a] + radii[slots[s]]);
+            }
+        }
+        if (cnt == 0) continue;
+        float flo[3], fhi[3];
+        for (int a = 0; a < 3; a++) {                            // inflate far beyond fp32 rounding of the slab test
+            const double m = 1e-4 * extent + 0.01 * (bhi[a] - blo[a]);
+            flo[a] = std::nextafter((float)(blo[a] - m), -INFINITY);
+            fhi[a] = std::nextafter((float)(bhi[a] + m), INFINITY);
+        }
+        c.h_groups[2 * g] = make_float4(flo[0], flo[1], flo[2], 0.0f);
+        c.h_groups[2 * g + 1] = make_float4(fhi[0], fhi[1], fhi[2], 0.0f);
+    }
 }
 
 void cleanup_impl() {
@@ -285,18 +390,9 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
     if (!spheres || !materials || n <= 0) rt_fail("initRendererSpheres: empty scene");
     c.is_spheres = true;
     default_options(&c.opt, 1);
-    c.n_spheres = n;
-    c.n_padded = (n + 63) & ~63;                // multiple of 64: one sphere per lane per round in the cooperative scan
-    // pad entries: radius 0 far away; additionally the kernel never accepts an index >= n
-    c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));
-    c.h_mat_color.resize(n);
-    c.h_mat_type.resize(n);
-    for (int k = 0; k < n; k++) {
-        c.h_spheres[k] = make_float4(spheres[k].center.e[0], spheres[k].center.e[1], spheres[k].center.e[2], spheres[k].radius);
-        c.h_mat_color[k] = make_float4(materials[k].color.e[0], materials[k].color.e[1], materials[k].color.e[2], materials[k].param);
+    for (int k = 0; k < n; k++)
         if (materials[k].type < RT_DIFFUSE || materials[k].type > RT_GLASS) rt_fail("initRendererSpheres: bad material type");
-        c.h_mat_type[k] = materials[k].type;
-    }
+    build_sphere_groups(spheres, materials, n);
     if (rt_sphere_kernel_lds_bytes(c.n_padded, n, 256) > 160 * 1024)
         rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 4400 spheres)");
     common_init(cam, fb, nx, ny, maxDepth);
@@ -346,8 +442,9 @@ void runRenderer(int ns, int tx, int ty) {
             RtSphereParams p;
             memset(&p, 0, sizeof p);
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
-            p.n = c.n_spheres; p.n_padded = c.n_padded;
+            p.n = c.n_spheres; p.n_padded = c.n_padded; p.n_groups = c.n_groups; p.n_big_groups = c.n_big_groups;
             p.spheres = d.d_spheres; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
+            p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
@@ -418,6 +515,7 @@ void runRenderer(int ns, int tx, int ty) {
             RtCounters h;
             HIP_CHECK(hipMemcpy(&h, d.d_counters, sizeof h, hipMemcpyDeviceToHost));
             st.rays += h.rays; st.prim_tests += h.prim_tests; st.node_visits += h.node_visits;
+            st.exec_tests += h.exec_tests;
         }
     }
     HIP_CHECK(hipSetDevice(current));

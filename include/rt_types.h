@@ -171,6 +171,7 @@ typedef struct rt_render_stats {
     uint64_t rays;          /* rays traced (only when built/launched with counters on; else 0)                  */
     uint64_t prim_tests;    /* sphere or triangle tests                                                         */
     uint64_t node_visits;   /* BVH internal-node visits                                                         */
+    uint64_t exec_tests;    /* sphere tests actually executed per lane after group culling (sphere scenes)     */
 } rt_render_stats;
 
 #endif /* RT_TYPES_H */
