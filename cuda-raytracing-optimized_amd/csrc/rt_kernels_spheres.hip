@@ -91,6 +91,7 @@ struct SceneLds {
     const int*    typ;      // n_padded
     const int*    orig;     // n_padded: the caller's sphere index of each slot (INT_MAX for pad slots)
     const int*    slot_of;  // n: slot of the caller's sphere index
+    const float*  rad;      // n_padded: radius (the hit normal divides by it: intersections.h:95)
     unsigned char* scratch; // kWavesPerWg x kWaveScratch bytes of per-wave work space (pair scan)
 };
 
@@ -100,22 +101,24 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     float4* s_mat = s_grp + 2 * P.n_groups;
     int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
     int*    s_org = s_typ + P.n_padded;
+    float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
+    int*    s_sof = reinterpret_cast<int*>(s_rad + P.n_padded);
     for (int k = threadIdx.x; k < P.n_padded; k += kThreads) {
         float4 s = P.spheres[k];
+        s_rad[k] = s.w;
         s.w = s.w * s.w;                                             // intersections.h:89 radius*radius
         s_sph[sidx(k)] = s;
         s_mat[k] = P.mat_color[k];
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
     }
-    int*    s_sof = s_org + P.n_padded;
     for (int k = threadIdx.x; k < 2 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
     for (int k = threadIdx.x; k < P.n; k += kThreads) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
     *after = s_fb;
     unsigned char* scratch = reinterpret_cast<unsigned char*>(s_fb + kThreads * 3);
     __syncthreads();
-    return { s_sph, s_grp, s_mat, s_typ, s_org, s_sof, scratch };
+    return { s_sph, s_grp, s_mat, s_typ, s_org, s_sof, s_rad, scratch };
 }
 
 // Per-lane path state (path, helper_structs.h:48-71, minus what sphere scenes never use).
@@ -286,7 +289,8 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     w_ray[2 * lane] = make_float4(org.x, org.y, org.z, a);
     w_ray[2 * lane + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
     w_best[lane] = (hb.sid >= 0) ? (((unsigned long long)__float_as_uint(hb.closest) << 32) | (unsigned long long)(uint32_t)hb.orig) : ~0ull;
-    const f3 inv = F3(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+    // v_rcp_f32 (1 ulp) is enough here: the slab test is conservative by 1e-5 relative
+    const f3 inv = F3(__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z));
 
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
         const int ng = min(kPassGroups, P.n_groups - g0);
@@ -400,7 +404,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const float closest = __uint_as_float((uint32_t)(w_best[q] >> 32));      // FLT_MAX-or-larger bit pattern if none: keeps everything
-        const f3 inv = F3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+        const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));   // conservative test: 1 ulp is fine
         // (b) one group box per lane, (c) 4 reachable groups per step, 16 lanes each
         for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += 64) {
             const int g = g0 + lane;
@@ -453,7 +457,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
         return true;
     }
     const float4 sc4 = S.sph[sidx(h.sid)];
-    const float radius = P.spheres[h.sid].w;                         // slot-indexed, like every scene array on the device
+    const float radius = S.rad[h.sid];                               // slot-indexed, like every scene array on the device
     const f3 hp = L.org + h.closest * dn;                            // ray.h:12 point_at_parameter
     f3 normal = (hp - F3(sc4.x, sc4.y, sc4.z)) / radius;             // intersections.h:95
     if (dot(dn, normal) > 0.0f) normal = -normal;                    // kernels.cu:354-355
@@ -572,9 +576,11 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
 // The persistent kernel ends with a tail in which every lane finishes the pixel it happens to hold.  That tail is short
 // when the LAST pixels handed out are cheap and alike.  A pixel whose centre ray (no lens offset, no jitter) misses every
 // sphere is almost surely a sky pixel: one ray per sample, the cheapest and most uniform work there is.  This kernel
-// sorts the tile-major pixel indices into two lists — list A "hits something" (handed out first, scattered), list B
-// "sky" (handed out last) — with one atomic per wave and list.  The lists only change WHO renders a pixel and WHEN,
-// never the result (the seed depends on the pixel id alone).  P.queue[4] / [5] = lengths of A / B.
+// sorts the tile-major pixel indices into three lists — class 0 "the centre ray crosses a glass sphere" (the pixels that
+// can need thousands of sequential rays: handed out first, scattered, so they run alongside everything else instead of
+// after it), class 1 "hits something else" (scattered), class 2 "sky" (last) — with one atomic per wave and list.  The
+// lists only change WHO renders a pixel and WHEN, never the result (the seed depends on the pixel id alone).
+// P.queue[4..6] = lengths of the lists.
 __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSphereParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
@@ -588,7 +594,7 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
     const int i = tx * 8 + (int)(within & 7u);
     const int lr = ty * 8 + (int)(within >> 3);
     const bool valid = p < total && i < P.nx && lr < P.part.local_rows;
-    bool hits = false;
+    bool hits = false, glass = false;
     if (valid) {
         const int j = global_row(P.part, lr);
         const float u = ((float)i + 0.5f) / (float)P.nx, v = ((float)j + 0.5f) / (float)P.ny;
@@ -599,22 +605,29 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
             const f3 oc = org - F3(sph.x, sph.y, sph.z);
             const float b = dot(oc, dn);
             const float c = dot(oc, oc) - sph.w;
-            hits = hits || ((S.orig[k] != 0x7fffffff) && (b * b - c > 0.0f) && (b < 0.0f || c < 0.0f));
+            const bool h = (S.orig[k] != 0x7fffffff) && (b * b - c > 0.0f) && (b < 0.0f || c < 0.0f);
+            hits = hits || h;
+            glass = glass || (h && S.typ[k] == RT_GLASS);
         }
     }
-    const unsigned long long ma = __ballot(valid && hits), mb = __ballot(valid && !hits);
-    uint32_t base_a = 0, base_b = 0;
+    // class 0: the centre ray crosses a glass sphere (candidates for very long paths) - handed out FIRST
+    // class 1: hits something else;  class 2: sky - handed out LAST
+    const int cls = glass ? 0 : (hits ? 1 : 2);
+    const unsigned long long m0 = __ballot(valid && cls == 0), m1 = __ballot(valid && cls == 1), m2 = __ballot(valid && cls == 2);
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
     if ((threadIdx.x & 63) == 0) {
-        if (ma) base_a = atomicAdd(P.queue + 4, (uint32_t)__popcll(ma));
-        if (mb) base_b = atomicAdd(P.queue + 5, (uint32_t)__popcll(mb));
+        if (m0) b0 = atomicAdd(P.queue + 4, (uint32_t)__popcll(m0));
+        if (m1) b1 = atomicAdd(P.queue + 5, (uint32_t)__popcll(m1));
+        if (m2) b2 = atomicAdd(P.queue + 6, (uint32_t)__popcll(m2));
     }
-    base_a = __builtin_amdgcn_readfirstlane(base_a);
-    base_b = __builtin_amdgcn_readfirstlane(base_b);
+    b0 = __builtin_amdgcn_readfirstlane(b0);
+    b1 = __builtin_amdgcn_readfirstlane(b1);
+    b2 = __builtin_amdgcn_readfirstlane(b2);
     if (valid) {
-        const unsigned long long m = hits ? ma : mb;
+        const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
+        const uint32_t base = cls == 0 ? b0 : (cls == 1 ? b1 : b2);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (hits) P.order[base_a + rank] = p;
-        else P.order[total + base_b + rank] = p;
+        P.order[(uint32_t)cls * total + base + rank] = p;
     }
 }
 
@@ -628,7 +641,7 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
 
 template <bool LEGACY>
 __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
-                                                                   int cull) {
+                                                                   int cull, int prio_after) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
     const SceneLds S = stage_scene(P, smem, &unused);
@@ -636,19 +649,22 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t padded = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
-    // classified order: queue positions [0, nA) walk list A in a scattered order, [nA, nA+nB) walk list B
-    const uint32_t nA = classified ? P.queue[4] : 0u, nB = classified ? P.queue[5] : 0u;
-    const uint32_t total = classified ? nA + nB : padded;
-    if (classified && nA > 64u) {                                    // stride ~ 0.618 nA, coprime with nA (wave-uniform)
-        uint32_t c = ((uint32_t)((unsigned long long)nA * 2654435769ull >> 32)) | 1u;
+    // classified order: queue positions [0, n0) walk class 0 (glass), [n0, n0+n1) class 1, both in a scattered order,
+    // then class 2 (sky) in list order
+    const uint32_t n0 = classified ? P.queue[4] : 0u, n1 = classified ? P.queue[5] : 0u, n2 = classified ? P.queue[6] : 0u;
+    const uint32_t total = classified ? n0 + n1 + n2 : padded;
+    auto coprime_stride = [](uint32_t n) {                           // ~0.618 n, coprime with n (wave-uniform)
+        if (n <= 64u) return 1u;
+        uint32_t c = ((uint32_t)((unsigned long long)n * 2654435769ull >> 32)) | 1u;
         for (;;) {
-            uint32_t a = c, b = nA;
+            uint32_t a = c, b = n;
             while (b) { const uint32_t t = a % b; a = b; b = t; }
             if (a == 1u) break;
             c += 2u;
         }
-        stride = c % nA;
-    }
+        return c % n;
+    };
+    const uint32_t stride0 = classified ? coprime_stride(n0) : 1u, stride1 = classified ? coprime_stride(n1) : 1u;
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -656,6 +672,8 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     int lr = 0;                         // local row of the lane's pixel (framebuffer row)
     uint32_t nrays = 0, groups_done = 0;
     bool have_pixel = false;            // lane owns an unfinished pixel
+    uint32_t pix_rays = 0;              // rays traced so far for the lane's current pixel
+    bool prio_raised = false;           // wave-uniform
     bool exhausted = false;             // wave-uniform: the global queue is empty
     float* fbf = reinterpret_cast<float*>(P.fb);
     // diagnostics (only when P.wave_dbg): 100 MHz time stamps and iteration counts of this wave
@@ -683,8 +701,9 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 const uint32_t pos = base + rank;
                 uint32_t p;
                 if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
-                else if (pos < nA) p = P.order[nA > 64u ? (uint32_t)(((unsigned long long)pos * stride) % nA) : pos];
-                else p = P.order[padded + (pos - nA)];
+                else if (pos < n0) p = P.order[(uint32_t)(((unsigned long long)pos * stride0) % n0)];
+                else if (pos < n0 + n1) p = P.order[padded + (uint32_t)(((unsigned long long)(pos - n0) * stride1) % n1)];
+                else p = P.order[2u * padded + (pos - n0 - n1)];
                 const uint32_t tile = p >> 6, within = p & 63u;
                 const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
                 const int i = tx * 8 + (int)(within & 7u);
@@ -692,6 +711,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
                     start_pixel(P, L, i, global_row(P.part, lr));
                     have_pixel = true;
+                    pix_rays = 0;
                 }
             }
         }
@@ -703,8 +723,19 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             if (__popcll(live_now) < coop_below) { dbg_coop_iters++; dbg_coop_rays += (uint32_t)__popcll(live_now); }
         }
 
+        // A pixel that has already needed many rays is one of the long sequential chains that decide when the frame
+        // ends (paths trapped in glass): the wave that holds one issues at raised priority, so the chain advances at
+        // close to single-wave speed while the SIMD's other waves fill the gaps.  Scheduling only: no effect on results.
+        if (prio_after > 0) {
+            const bool heavy = __ballot(have_pixel && pix_rays > (uint32_t)prio_after) != 0ull;
+            if (heavy != prio_raised) {
+                if (heavy) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+                prio_raised = heavy;
+            }
+        }
+
         // ---- one ray per live lane ----------------------------------------------------------------------------
-        if (have_pixel) nrays++;
+        if (have_pixel) { nrays++; pix_rays++; }
         const bool done = trace_rays<LEGACY>(P, S, L, have_pixel, coop_below, cull != 0, groups_done);
         if (have_pixel && done) {
             L.col = L.col + L.pcolor;                                // kernels.cu:558
@@ -738,7 +769,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
 
 static size_t lds_bytes(int n_padded, int n) {
     // spheres + group bounds + material colour + type + original index per slot, + fb staging of the tile kernel
-    return (size_t)(n_padded + n_padded / 16) * 16 + (size_t)(n_padded / 16) * 32 + (size_t)n_padded * 16 + (size_t)n_padded * 8 +
+    return (size_t)(n_padded + n_padded / 16) * 16 + (size_t)(n_padded / 16) * 32 + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
            (size_t)((n + 3) & ~3) * 4 + (size_t)kThreads * 3 * 4 + (size_t)kWavesPerWg * kWaveScratch;
 }
 
@@ -750,7 +781,7 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n, int threads) {
 #endif
 
 // variant: bits 0..7   kernel: 0 = persistent waves + pixel queue (default), 1 = one tile per wave;
-//          bits 8..15  workgroups per CU of the persistent kernel (0 = default 4);
+//          bits 8..15  workgroups per CU of the persistent kernel (0 = default 3);
 //          bits 16..23 0 = pair-compacted scan + sparse form (default); 255 = pair-compacted scan only.  Otherwise the earlier hybrid: lane-parallel scan, switching
 //                      to the wave-cooperative scan when fewer than this many lanes of a wave have a ray
 //                      (1 = never cooperative, 65 = always cooperative);
@@ -770,6 +801,9 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         if (e != hipSuccess) return e;
     }
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
+    // bits 27..29: raise the issue priority of waves that hold a pixel with more than 100 << (bits-1) rays (0 = off: measured no gain)
+    const int pb = (variant >> 27) & 7;
+    const int prio_after = (pb == 7 || pb == 0) ? 0 : (100 << (pb - 1));
     int coop_below = (variant >> 16) & 0xFF;
     if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
     if (coop_below == 255) coop_below = -2;    // pair-compacted scan only (A/B)
@@ -785,7 +819,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 4;
+    if (wg_per_cu == 0) wg_per_cu = 3;      // = the residency the kernel's VGPR budget (168) and LDS (~46 KB) allow
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + kThreads - 1) / kThreads;      // never more lanes than pixels
@@ -806,7 +840,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
-    if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull);
-    else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull);
+    if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, prio_after);
+    else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, prio_after);
     return hipGetLastError();
 }

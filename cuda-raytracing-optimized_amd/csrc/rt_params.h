@@ -48,7 +48,7 @@ struct RtSphereParams {
     RtCounters* counters;       // nullptr = off
     uint32_t* queue;            // one zero-initialised word: next unassigned pixel (persistent-wave kernels)
     unsigned long long* wave_dbg;   // nullptr, or 8 x u64 per wave: diagnostic time stamps (RT_WAVE_DEBUG)
-    uint32_t* order;            // 2 * padded pixel count words: work-order lists built by the classify pre-pass
+    uint32_t* order;            // 3 * padded pixel count words: work-order lists built by the classify pre-pass
 };
 
 struct RtMeshParams {

@@ -191,9 +191,9 @@ void setup_devices() {
         const int world = c.opt.part_world * nd, rank = c.opt.part_rank * nd + k;
         d.fb_rows = (size_t)local_rows_of(c.ny, c.opt.stripe_rows, rank, world);
         if (d.fb_rows > 0) HIP_CHECK(hipMalloc((void**)&d.d_fb, d.fb_rows * c.nx * sizeof(rt_vec3)));
-        if (d.fb_rows > 0) {        // work-order lists of the persistent kernels: 2 x (pixels padded to 8x8 tiles)
+        if (d.fb_rows > 0) {        // work-order lists of the persistent kernels: 3 x (pixels padded to 8x8 tiles)
             const size_t padded = (size_t)((c.nx + 7) / 8) * ((d.fb_rows + 7) / 8) * 64;
-            HIP_CHECK(hipMalloc((void**)&d.d_order, 2 * padded * sizeof(uint32_t)));
+            HIP_CHECK(hipMalloc((void**)&d.d_order, 3 * padded * sizeof(uint32_t)));
         }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
         HIP_CHECK(hipMemset(d.d_counters, 0, sizeof(RtCounters)));
