@@ -276,11 +276,323 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) 
     }
 }
 
+
+// ---- variant 0 (default): persistent waves, pixel queue, ray-job state machine ---------------------------------------
+// The first kernel (above) nests two traversals (closest hit, then the shadow ray) inside one loop iteration and lets a
+// lane whose traversal ended wait for the slowest lane of the wave: rocprof showed 17 % of the lanes active per VALU
+// instruction.  Here every lane owns a JOB = one ray to traverse (closest-hit or shadow, same code) and the wave
+// alternates between two phases:
+//   TRAVERSE  while at least `kMinTraversing` lanes still have nodes to visit: "while-while" steps — all lanes descend
+//             internal nodes together until each sits on a leaf (or is done), then all lanes test their leaf's triangles.
+//             The per-lane visiting order is exactly hitBvh's (kernels.cu:154-224), only the control flow is regrouped;
+//   PROCESS   the lanes whose traversal has ended consume the result (scatter + next-event estimation + Russian roulette
+//             exactly in the reference's order, kernels.cu:415-527) and set up their next job: the shadow ray, the next
+//             bounce, the next sample, or the next pixel from the global queue (ballot + mbcnt allocation).
+// Lanes that are still traversing simply keep their state across a PROCESS phase.
+constexpr int kMinTraversing = 40;
+
+struct Job {
+    Ray r;
+    int idx;                // 0 = traversal finished
+    uint32_t bitStack;
+    float closest;          // running closest t (t_max at start)
+    float t_min;
+    uint32_t triId;
+    float hu, hv;
+    bool shadow;
+};
+
+__device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org, f3 dir, float t_min, float t_max, bool shadow) {
+    J.r = make_ray(org, dir);
+    J.shadow = shadow;
+    J.t_min = t_min;
+    J.closest = t_max;
+    J.bitStack = 1;
+    J.triId = 0; J.hu = 0.0f; J.hv = 0.0f;
+    // hitMesh, kernels.cu:296-323: scene bounds first; a miss reports FLT_MAX
+    if (hit_bbox(ld3(P.bounds.min), ld3(P.bounds.max), J.r, t_max)) {
+        J.idx = 1;
+    } else {
+        J.idx = 0;
+        J.closest = FLT_MAX;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing) {
+    const int tiles_x = (P.nx + 7) >> 3;
+    const int tiles_y = (P.part.local_rows + 7) >> 3;
+    const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+    const float eps = P.t_min;
+    const f3 lightC = ld3(P.light.center);
+    const float lightR = P.light.radius;
+    float* fbf = reinterpret_cast<float*>(P.fb);
+
+    // path state (path, helper_structs.h:48-71)
+    uint32_t rng = 1;
+    f3 col = F3(0, 0, 0), org = F3(0, 0, 0), dir = F3(0, 0, 1), atten = F3(1, 1, 1), pcolor = F3(0, 0, 0);
+    f3 pend_contrib = F3(0, 0, 0);      // lightContribution of the pending shadow ray
+    float pend_dist = 0.0f;
+    int bounce = 0, s = 0, pi = 0, pj = 0, lr = 0;
+    bool inside = false, specular = false;
+    uint32_t pixelId = 0;
+    Job J;
+    J.idx = 0; J.shadow = false; J.closest = FLT_MAX; J.bitStack = 1; J.t_min = eps; J.triId = 0; J.hu = J.hv = 0.0f;
+    J.r.o = F3(0, 0, 0); J.r.d = F3(0, 0, 1); J.r.inv = F3(0, 0, 1);
+    bool have_pixel = false, exhausted = false;
+    TravStats st = { 0, 0 };
+    uint32_t nrays = 0, nshadow = 0;
+
+    auto start_sample = [&]() {                                      // kernels.cu:549-555, 397-398
+        if (P.rng_mode == RT_RNG_COUNTER) rng = sample_seed(pixelId, (uint32_t)s);
+        const float u = ((float)pi + rnd(rng)) / (float)P.nx;
+        const float v = ((float)pj + rnd(rng)) / (float)P.ny;
+        f3 d;
+        get_ray(P.cam, u, v, rng, org, d);
+        dir = unit(d);
+        atten = F3(1.0f, 1.0f, 1.0f);
+        pcolor = F3(0, 0, 0);
+        bounce = 0;
+        inside = false;
+        specular = false;
+        nrays++;
+        job_start(P, J, org, dir, eps, FLT_MAX, false);             // hit(context, p, FLT_MAX, false, ...)
+    };
+
+    while (true) {
+        // ================= PROCESS: lanes without a running traversal =======================================
+        if (have_pixel && J.idx == 0) {
+            bool path_done = false;
+            bool next_ray = false;                                   // continue the path with a new closest-hit job
+            if (!J.shadow) {
+                const float t = J.closest;
+                if (t < FLT_MAX) {
+                    const Tri tri = load_tri(P.tris, J.triId);       // kernels.cu:334
+                    f3 normal = unit(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                    const float w0 = 1 - J.hu - J.hv;
+                    const float tcu = (J.hu * tri.tc[2] + J.hv * tri.tc[4] + w0 * tri.tc[0]);
+                    const float tcv = (J.hu * tri.tc[3] + J.hv * tri.tc[5] + w0 * tri.tc[1]);
+                    if (dot(J.r.d, normal) > 0.0f) normal = -normal; // kernels.cu:354-355
+                    const rt_material mat = P.materials[tri.meshID]; // kernels.cu:452-480
+                    f3 albedo;
+                    if (mat.texId != -1) {
+                        const int width = P.tex_width[mat.texId];
+                        const int height = P.tex_height[mat.texId];
+                        float tu = tcu; tu = tu - floorf(tu);
+                        float tv = tcv; tv = tv - floorf(tv);
+                        const int tx = (int)((float)(width - 1) * tu);
+                        const int ty = (int)((float)(height - 1) * tv);
+                        const int tIdx = ty * width + tx;
+                        const float* d = P.tex_data[mat.texId];
+                        albedo = F3(d[tIdx * 3 + 0], d[tIdx * 3 + 1], d[tIdx * 3 + 2]);
+                    } else {
+                        albedo = ld3(mat.color);
+                    }
+                    Scatter sc;
+                    material_scatter(sc, t, normal, inside, dir, mat.type, albedo, mat.param, rng);
+                    org = org + sc.t * dir;                          // kernels.cu:485-489
+                    dir = sc.wi;
+                    atten = atten * sc.throughput;
+                    specular = sc.specular;
+                    inside = sc.refracted ? !inside : inside;
+
+                    bool shadow_job = false;
+                    if (P.nee && !specular) {                        // generateShadowRay, kernels.cu:363-393
+                        const f3 sw = unit(lightC - org);
+                        const f3 su = unit(cross(fabsf(sw.x) > 0.01f ? F3(0, 1, 0) : F3(1, 0, 0), sw));
+                        const f3 sv = cross(sw, su);
+                        const float cosAMax = rt_sqrt(1.0f - lightR * lightR / sqlen(org - lightC));
+                        if (!isnan(cosAMax)) {
+                            const float eps1 = rnd(rng);
+                            const float eps2 = rnd(rng);
+                            const float cosA = 1.0f - eps1 + eps1 * cosAMax;
+                            const float sinA = rt_sqrt(1.0f - cosA * cosA);
+                            const float phi = (float)(2 * M_PI * (double)eps2);
+                            const float cphi = (float)cos((double)phi), sphi = (float)sin((double)phi);
+                            const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
+                            const float dotl = dot(l, normal);
+                            if (dotl > 0) {
+                                const f3 shadowDir = unit(l);
+                                const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));
+                                pend_contrib = (omega * (dotl * (atten * ld3(P.lightColor)))) / (float)M_PI;
+                                pend_dist = len(lightC - org) - lightR;
+                                nshadow++;
+                                job_start(P, J, org, shadowDir, eps, pend_dist, true);   // hit(context, p, lightDist, true, ...)
+                                shadow_job = true;
+                            }
+                        }
+                    }
+                    if (!shadow_job) next_ray = true;                // falls through to Russian roulette below
+                } else if (specular && sphere_hit(lightC, lightR, J.r, eps, FLT_MAX) < FLT_MAX) {   // kernels.cu:346
+                    if (!P.nee) pcolor = pcolor + atten * ld3(P.lightColor);                        // kernels.cu:440-446
+                    path_done = true;
+                } else {
+                    pcolor = pcolor + atten * sky_color(P.sky, dir);                                // kernels.cu:419-425
+                    path_done = true;
+                }
+            } else {
+                // shadow traversal finished: hitMesh returned J.closest; "hit" means closest < lightDist (kernels.cu:331,504-510)
+                if (!(J.closest < pend_dist)) pcolor = pcolor + pend_contrib;
+                J.shadow = false;
+                next_ray = true;
+            }
+            if (next_ray) {
+                if (P.rr && bounce > 3) {                            // kernels.cu:512-527
+                    const float mx = max3(atten);
+                    if (rnd(rng) > mx) {
+                        path_done = true;
+                    } else {
+                        const float kk = 1.0f / mx;
+                        atten = F3(atten.x * kk, atten.y * kk, atten.z * kk);
+                    }
+                }
+                bounce++;
+                if (bounce >= P.max_depth) path_done = true;         // loop bound, kernels.cu:402
+                if (!path_done) {
+                    nrays++;
+                    job_start(P, J, org, dir, eps, FLT_MAX, false);
+                }
+            }
+            if (path_done) {
+                col = col + pcolor;                                  // kernels.cu:558
+                s++;
+                if (s < P.ns) {
+                    start_sample();
+                } else {
+                    const f3 out = col / (float)P.ns;                // kernels.cu:568
+                    float* dst = fbf + ((size_t)lr * P.nx + pi) * 3;
+                    dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+                    have_pixel = false;
+                }
+            }
+        }
+
+        // ================= refill idle lanes from the global pixel queue ======================================
+        while (!exhausted) {
+            const unsigned long long need = __ballot(!have_pixel);
+            if (need == 0ull) break;
+            const uint32_t cnt = (uint32_t)__popcll(need);
+            uint32_t base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total) { exhausted = true; break; }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (base + cnt >= total) exhausted = true;
+            if (!have_pixel && base + rank < total) {
+                const uint32_t p = (uint32_t)(((unsigned long long)(base + rank) * stride) % total);
+                const uint32_t tile = p >> 6, within = p & 63u;
+                const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
+                const int i = tx * 8 + (int)(within & 7u);
+                lr = ty * 8 + (int)(within >> 3);
+                if (i < P.nx && lr < P.part.local_rows) {
+                    pi = i; pj = global_row(P.part, lr);
+                    pixelId = (uint32_t)(pj * P.nx + pi);
+                    rng = pixel_seed(pixelId);
+                    col = F3(0, 0, 0);
+                    s = 0;
+                    have_pixel = true;
+                    start_sample();
+                }
+            }
+        }
+        if (__ballot(have_pixel) == 0ull) break;
+
+        // ================= TRAVERSE ================================================================================
+        // at least once; keep going while enough lanes have nodes left (the others wait for the next PROCESS phase)
+        do {
+            // descend: internal nodes (kernels.cu:162-195)
+            while (have_pixel && J.idx != 0 && (uint32_t)J.idx < P.first_leaf) {
+                const int idx2 = J.idx << 1;
+                const float4* n = P.bvh4 + (size_t)J.idx * 3;
+                const float4 na = n[0], nb = n[1], nc = n[2];
+                st.nodes++;
+                const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest);
+                const bool traverseLeft = leftHit < J.closest;
+                const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest);
+                const bool traverseRight = rightHit < J.closest;
+                const bool swap = rightHit < leftHit;
+                if (traverseLeft && traverseRight) {
+                    J.idx = idx2 + (swap ? 1 : 0);
+                    J.bitStack = (J.bitStack << 1) + 1;
+                } else if (traverseLeft || traverseRight) {
+                    J.idx = idx2 + (swap ? 1 : 0);
+                    J.bitStack = J.bitStack << 1;
+                } else {
+                    const int m = __ffs((int)J.bitStack) - 1;        // pop_bitstack, kernels.cu:148-152
+                    J.bitStack = (J.bitStack >> m) ^ 1u;
+                    J.idx = (J.idx >> m) ^ 1;
+                }
+            }
+            // leaf (kernels.cu:196-214)
+            if (have_pixel && J.idx != 0) {
+                const uint32_t first = ((uint32_t)J.idx - P.first_leaf) * P.nppl;
+                bool occluded = false;
+                for (uint32_t k = 0; k < P.nppl; k++) {
+                    const float4* pt = reinterpret_cast<const float4*>(P.tris + first + k);
+                    const float4 a = pt[0], b = pt[1];
+                    if (isinf(a.x)) break;                           // kernels.cu:202 sentinel
+                    const float cx = pt[2].x;
+                    float u, v;
+                    st.tests++;
+                    const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
+                    if (hitT < J.closest) {
+                        if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
+                        J.closest = hitT;
+                        J.triId = first + k;
+                        J.hu = u; J.hv = v;
+                    }
+                }
+                if (occluded) {
+                    J.closest = 0.0f;
+                    J.idx = 0;
+                } else {
+                    const int m = __ffs((int)J.bitStack) - 1;
+                    J.bitStack = (J.bitStack >> m) ^ 1u;
+                    J.idx = (J.idx >> m) ^ 1;
+                }
+            }
+        } while (__popcll(__ballot(have_pixel && J.idx != 0)) >= min_traversing);
+    }
+
+    if (P.counters) {
+        atomicAdd(&P.counters->rays, (unsigned long long)nrays);
+        atomicAdd(&P.counters->shadow_rays, (unsigned long long)nshadow);
+        atomicAdd(&P.counters->prim_tests, (unsigned long long)st.tests);
+        atomicAdd(&P.counters->node_visits, (unsigned long long)st.nodes);
+    }
+}
+
 }  // namespace
 
+// variant: bits 0..7  0 = persistent state-machine kernel (default), 1 = first kernel (one tile per wave);
+//          bits 8..15 workgroups per CU of the persistent kernel (0 = default 4);
+//          bits 16..23 keep traversing while at least this many lanes have nodes left (0 = default 40).
 hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream) {
-    (void)variant;
-    const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
-    hipLaunchKernelGGL(k_render_mesh<0>, grid, dim3(kThreads), 0, stream, p);
+    if ((variant & 0xFF) == 1) {
+        const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
+        hipLaunchKernelGGL(k_render_mesh<0>, grid, dim3(kThreads), 0, stream, p);
+        return hipGetLastError();
+    }
+    if (!p.queue) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(p.queue, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int wg_per_cu = (variant >> 8) & 0xFF;
+    if (wg_per_cu == 0) wg_per_cu = 4;
+    const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
+    long long blocks = (long long)cus * wg_per_cu;
+    const long long useful = (total_px + kThreads - 1) / kThreads;
+    if (blocks > useful) blocks = useful;
+    if (blocks < 1) blocks = 1;
+    uint32_t stride = 1;
+    if (total_px > 64) {
+        auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
+        unsigned long long cand = (unsigned long long)((double)total_px * 0.6180339887) | 1ull;
+        while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
+        stride = (uint32_t)(cand % (unsigned long long)total_px);
+    }
+    int min_traversing = (variant >> 16) & 0xFF;
+    if (min_traversing == 0) min_traversing = kMinTraversing;
+    hipLaunchKernelGGL(k_render_mesh_queue, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing);
     return hipGetLastError();
 }

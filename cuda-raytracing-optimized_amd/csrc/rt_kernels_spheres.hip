@@ -282,9 +282,15 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);
     const float t_min = P.t_min;
 
+    // 1. big spheres: plain sphereHit per real slot (there are only a few; pad slots of the last big group are skipped)
     Hit hb = { FLT_MAX, -1, 0x7fffffff };
-    if (has_ray)
-        for (int g = 0; g < P.n_big_groups; g++) { groups_done++; scan_group_broadcast(P, S, g, org, dn, a, hb); }
+    if (has_ray) {
+        groups_done += (uint32_t)P.n_big_groups;
+        for (int k = 0; k < P.n_big; k++) {
+            const float t = sphere_hit_exact(S.sph[sidx(k)], org, dn, a, t_min, hb.closest);   // wave-uniform address: LDS broadcast
+            if (t < FLT_MAX) accept(hb, t, k, S.orig[k]);
+        }
+    }
 
     w_ray[2 * lane] = make_float4(org.x, org.y, org.z, a);
     w_ray[2 * lane + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);

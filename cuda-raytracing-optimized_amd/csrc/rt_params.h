@@ -33,6 +33,7 @@ struct RtSphereParams {
     int32_t n_padded;           // slots: multiple of 64; slots are grouped 16 by 16 (pad slots can never be hit)
     int32_t n_groups;           // n_padded / 16
     int32_t n_big_groups;       // groups [0, n_big_groups) hold the big spheres: always scanned
+    int32_t n_big;              // real big spheres: slots [0, n_big)
     const float4* spheres;      // n_padded x (cx, cy, cz, radius), spatially sorted (see rt_renderer.hip build_sphere_groups)
     const float4* groups;       // 2 x n_groups: inflated AABB (lo.xyz, hi.xyz) of each group
     const float4* mat_color;    // n_padded x (r, g, b, param)

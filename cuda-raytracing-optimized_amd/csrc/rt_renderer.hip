@@ -83,7 +83,7 @@ struct RenderContext {
     std::vector<float4> h_groups;       // two float4 per group of 16 slots: inflated AABB lo / hi
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
-    int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0;
+    int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0, n_big = 0;
     std::vector<rt_triangle> h_tris;
     std::vector<float4> h_bvh;          // numBvhNodes * 24 B viewed as float4 (padded)
     int num_bvh_nodes = 0;
@@ -283,6 +283,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     c.n_padded = (int)slots.size();
     c.n_groups = c.n_padded / 16;
     c.n_big_groups = n_big_groups;
+    c.n_big = (int)big.size();
     c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));      // pad: radius 0, far away
     c.h_mat_color.assign(c.n_padded, make_float4(0, 0, 0, 0));
     c.h_mat_type.assign(c.n_padded, RT_DIFFUSE);
@@ -442,7 +443,7 @@ void runRenderer(int ns, int tx, int ty) {
             RtSphereParams p;
             memset(&p, 0, sizeof p);
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
-            p.n = c.n_spheres; p.n_padded = c.n_padded; p.n_groups = c.n_groups; p.n_big_groups = c.n_big_groups;
+            p.n = c.n_spheres; p.n_padded = c.n_padded; p.n_groups = c.n_groups; p.n_big_groups = c.n_big_groups; p.n_big = c.n_big;
             p.spheres = d.d_spheres; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.fb = d.d_fb; p.part = part;

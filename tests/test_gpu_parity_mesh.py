@@ -31,24 +31,26 @@ def _render_gpu(rt, hm, mats, cam, nx, ny, ns, depth, **opts):
     return out, st
 
 
-def test_mesh_no_nee_bit_exact(rt, O, stair):
+@pytest.mark.parametrize("variant", [0, 1, (1 << 8), (8 << 8)])       # 0 = persistent state machine, 1 = tile per wave; bits 8.. = WGs per CU
+def test_mesh_no_nee_bit_exact(rt, O, stair, variant):
     hm, mats = stair
     nx, ny, ns = 96, 120, 2
     cam = rt.staircase_camera(nx, ny)
     o = O.default_options(False)
     o.nee = 0
     ref, cnt = O.render(O.mesh_scene(hm, mats), cam, o, nx, ny, ns, 16, counters=True)
-    got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 16, nee=0, counters=1)
+    got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 16, nee=0, counters=1, variant=variant)
     assert np.array_equal(_bits(got), _bits(ref)), f"{np.count_nonzero(_bits(got) != _bits(ref))} differing words"
     assert st.rays == cnt.rays and st.node_visits == cnt.node_visits and st.prim_tests == cnt.prim_tests
 
 
-def test_mesh_nee_rr_within_tolerance(rt, O, stair):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_mesh_nee_rr_within_tolerance(rt, O, stair, variant):
     hm, mats = stair
     nx, ny, ns = 96, 120, 2
     cam = rt.staircase_camera(nx, ny)
     ref, cnt = O.render(O.mesh_scene(hm, mats), cam, O.default_options(False), nx, ny, ns, 64, counters=True)
-    got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1)
+    got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1, variant=variant)
     rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
     assert rel.mean() >= 0.999, rel.mean()
     assert abs(int(st.rays) - int(cnt.rays)) <= 0.001 * cnt.rays
@@ -75,3 +77,39 @@ def test_drop_in_link_against_reference_headers(rt, O, stair, tmp_path):
     ref, _ = O.render(O.mesh_scene(hm, mats), cam, O.default_options(False), nx, ny, ns, depth)
     rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
     assert rel.mean() >= 0.999
+
+
+def test_mesh_variants_agree_bit_for_bit_with_nee(rt, stair):
+    """Both kernels run the same device functions in the same per-lane order: with NEE + RR on (cos/sin included)
+    they must agree with each other exactly, and textures (nearest texel, kernels.cu:456-476) too."""
+    hm, mats = stair
+    nx, ny, ns = 80, 96, 3
+    cam = rt.staircase_camera(nx, ny)
+    a, sa = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1, variant=0)
+    b, sb = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1, variant=1)
+    assert np.array_equal(_bits(a), _bits(b))
+    assert (sa.rays, sa.node_visits, sa.prim_tests) == (sb.rays, sb.node_visits, sb.prim_tests)
+
+
+def test_mesh_textures_bit_exact(rt, O, stair):
+    """Albedo textures: nearest texel with wrap (kernels.cu:456-476), NEE off so the comparison is exact."""
+    hm, mats = stair
+    mats = mats.copy()
+    rng = np.random.default_rng(3)
+    tex = [rng.uniform(0, 1, (16, 24, 3)).astype(np.float32), rng.uniform(0, 1, (7, 5, 3)).astype(np.float32)]
+    mats["texId"][17] = 0       # floor
+    mats["texId"][13] = 1       # back wall
+    mats["texId"][19] = 0       # stairs
+    nx, ny, ns = 72, 90, 2
+    cam = rt.staircase_camera(nx, ny)
+    o = O.default_options(False)
+    o.nee = 0
+    ref, _ = O.render(O.mesh_scene(hm, mats, tex), cam, o, nx, ny, ns, 12)
+    ks, keep = rt.make_kernel_scene(hm, mats, tex)
+    fb = rt.initRenderer(ks, cam, nx, ny, 12, keepalive=keep)
+    oo = rt.getDefaultRenderOptions(False)
+    rt.setRenderOptions(oo, nee=0)
+    rt.runRenderer(ns, 8, 8)
+    got = np.array(fb, copy=True)
+    rt.cleanupRenderer()
+    assert np.array_equal(_bits(got), _bits(ref))
