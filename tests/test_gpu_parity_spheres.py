@@ -132,3 +132,50 @@ def test_rerun_is_deterministic(rt):
     b = np.array(fb, copy=True)
     rt.cleanupRenderer()
     assert np.array_equal(_bits(a), _bits(b))
+
+
+def _random_scene(rt, rng, n, big=1, dup=0):
+    sp = np.zeros(n, rt.sphere_dtype)
+    mt = np.zeros(n, rt.material_dtype)
+    sp["center"] = rng.uniform(-6, 6, (n, 3)) * (1, 0.3, 1)
+    sp["radius"] = rng.uniform(0.1, 0.45, n)
+    for k in range(min(big, n)):
+        sp["center"][k] = (0, -500.5 - k, 0) if k == 0 else rng.uniform(-3, 3, 3)
+        sp["radius"][k] = 500 if k == 0 else 1.5
+    for k in range(dup):                                   # exact duplicates LATER in the list: the first index must win
+        src = big + k
+        dst = n - 1 - k
+        if dst > src:
+            sp[dst] = sp[src]
+    mt["type"] = rng.integers(0, 3, n)
+    mt["color"] = rng.uniform(0.1, 1, (n, 3))
+    mt["param"] = np.where(mt["type"] == rt.RT_GLASS, 1.5, rng.uniform(0, 0.3, n))
+    mt["texId"] = -1
+    return sp, mt
+
+
+@pytest.mark.parametrize("n,big,dup", [(1, 1, 0), (2, 0, 0), (17, 1, 3), (33, 0, 5), (64, 2, 0), (65, 1, 8), (300, 3, 20), (1500, 1, 0)])
+def test_arbitrary_sphere_scenes_bit_exact(rt, O, n, big, dup):
+    """Scene shapes the benchmark does not have: 1 sphere, no big spheres, only a few small ones, group counts
+    that are not multiples of 4, > 1024 spheres, and EXACT duplicate spheres with different materials (an exact
+    tie in t: the reference's strict `<` keeps the lower index — the Morton re-ordering must not change that)."""
+    rng = np.random.default_rng(1000 + n)
+    sp, mt = _random_scene(rt, rng, n, big, dup)
+    nx, ny, ns = 96, 64, 3
+    cam = rt.make_camera((9, 3, 7), (0, 0, 0), (0, 1, 0), 35.0, nx / ny, 0.05, 10.0)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 20, counters=True)
+    for variant in (0, 1 << 26, (24 << 16)):
+        got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 20, counters=1, variant=variant)
+        assert np.array_equal(_bits(got), _bits(ref)), (variant, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert st.rays == cnt.rays
+
+
+def test_camera_inside_scene_and_odd_image_sizes(rt, O):
+    """Camera inside the sphere cloud (rays start inside group boxes), image sizes that are not multiples of 8."""
+    rng = np.random.default_rng(77)
+    sp, mt = _random_scene(rt, rng, 200, 1, 0)
+    for nx, ny in ((37, 21), (8, 8), (9, 1), (1, 9)):
+        cam = rt.make_camera((0.3, 0.4, 0.2), (2, 0.2, 1), (0, 1, 0), 70.0, nx / ny, 0.0, 1.0)
+        ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, 4, 12)
+        got, _ = _render_gpu(rt, sp, mt, cam, nx, ny, 4, 12)
+        assert np.array_equal(_bits(got), _bits(ref)), (nx, ny)
