@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) 
                     const float cosA = 1.0f - eps1 + eps1 * cosAMax;
                     const float sinA = rt_sqrt(1.0f - cosA * cosA);
                     const float phi = (float)(2 * M_PI * (double)eps2);
-                    // cosf/sinf of the reference: evaluated in fp64 and rounded once (libm vs OCML differ by ulps otherwise)
-                    const float cphi = (float)cos((double)phi), sphi = (float)sin((double)phi);
+                    float sphi, cphi;
+                            sincosf(phi, &sphi, &cphi);   // OCML fp32 (<= 2 ulp); glibc's cosf/sinf on the CPU side differ by ulps: tolerance, see tests
                     const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
                     const float dotl = dot(l, normal);
                     if (dotl > 0) {
@@ -318,7 +318,7 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
     }
 }
 
-__global__ void __launch_bounds__(kThreads) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing) {
+__global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
@@ -407,7 +407,8 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh_queue(const RtMeshPara
                             const float cosA = 1.0f - eps1 + eps1 * cosAMax;
                             const float sinA = rt_sqrt(1.0f - cosA * cosA);
                             const float phi = (float)(2 * M_PI * (double)eps2);
-                            const float cphi = (float)cos((double)phi), sphi = (float)sin((double)phi);
+                            float sphi, cphi;
+                            sincosf(phi, &sphi, &cphi);   // OCML fp32 (<= 2 ulp); glibc's cosf/sinf on the CPU side differ by ulps: tolerance, see tests
                             const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
                             const float dotl = dot(l, normal);
                             if (dotl > 0) {
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh_queue(const RtMeshPara
 }  // namespace
 
 // variant: bits 0..7  0 = persistent state-machine kernel (default), 1 = first kernel (one tile per wave);
-//          bits 8..15 workgroups per CU of the persistent kernel (0 = default 4);
+//          bits 8..15 workgroups per CU of the persistent kernel (0 = default 5);
 //          bits 16..23 keep traversing while at least this many lanes have nodes left (0 = default 40).
 hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream) {
     if ((variant & 0xFF) == 1) {
@@ -578,7 +579,7 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 4;
+    if (wg_per_cu == 0) wg_per_cu = 5;      // launch bound: 5 waves per SIMD (96 VGPRs); 6 gave the same rate, 8 spills
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + kThreads - 1) / kThreads;
