@@ -9,8 +9,9 @@ A "step" is one full frame of the workload rendered through the C-ABI
   N = 1   BASELINE.json configs[1]: random-spheres (488 spheres), 1200x800, 100 spp, maxDepth 50.
   N > 1   weak scaling: the same scene, 100 spp, 3:2 image whose AREA grows with N (~960 k pixels per
           GPU); the image is cut into interleaved 8-row stripes, rank r renders stripes k = r (mod N)
-          (no collective on the data path) and the stripes are gathered on the host into one shared
-          framebuffer (plain memcpy through /dev/shm).  Launched by the driver as
+          (no collective on the data path) and the stripes are gathered on the host: the ranks share one
+          framebuffer in /dev/shm, page-locked by every rank, and each rank's device-to-host stripe copies
+          (hipMemcpy2DAsync inside runRenderer) land in it directly.  Launched by the driver as
           `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
@@ -103,7 +104,7 @@ def main():
     shared = None
     if world > 1:
         shared = multigpu.SharedFramebuffer(f"bench_{os.environ.get('MASTER_PORT', '0')}", nx, ny, rank, dist.barrier)
-    my_rows = multigpu.stripe_rows(rank, world, ny)
+        rt.setExternalFramebuffer(shared.array)     # every rank's D2H stripe copies land in the one shared framebuffer
 
     def sync():
         if world > 1:
@@ -111,9 +112,7 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        rt.runRenderer(SPP, 8, 8)                # blocking: kernel + D2H of this rank's stripes
-        if shared is not None:
-            shared.gather(fb, my_rows)           # host-side gather (no RCCL)
+        rt.runRenderer(SPP, 8, 8)                # blocking: kernel + D2H (hipMemcpy2DAsync) of this rank's stripes = the host gather
 
     # one counted run (untimed): rays per frame for the algorithmic flop count
     rt.setRenderOptions(opt, counters=1)

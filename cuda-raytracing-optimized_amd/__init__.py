@@ -113,7 +113,8 @@ assert triangle_dtype.itemsize == 64 and bvh_node_dtype.itemsize == 24
 
 # symbols every library must export (tests check the .so against the headers with these)
 RENDERER_SYMBOLS = ["initRenderer", "runRenderer", "cleanupRenderer", "initRendererSpheres",
-                    "getDefaultRenderOptions", "setRenderOptions", "getRenderStats", "rtDeviceCount", "rtApiVersion"]
+                    "getDefaultRenderOptions", "setRenderOptions", "setExternalFramebuffer", "getRenderStats",
+                    "rtDeviceCount", "rtApiVersion"]
 HOST_SYMBOLS = ["rtMakeCamera", "rtRandomFloat", "rtSceneThreeSpheres", "rtSceneRandomSpheres", "rtStaircaseCamera",
                 "rtBuildBvh", "rtLoadBvhFile", "rtSaveBvhFile", "rtFreeMesh", "rtMeshView",
                 "rtSceneStaircaseProcedural", "rtLinearToSRGB", "rtWritePPM", "rtSaveReference", "rtLoadReference", "rtRmse"]
@@ -187,6 +188,8 @@ def load_renderer():
         r.getDefaultRenderOptions.restype = None
         r.setRenderOptions.argtypes = [C.POINTER(render_options)]
         r.setRenderOptions.restype = None
+        r.setExternalFramebuffer.argtypes = [C.c_void_p]
+        r.setExternalFramebuffer.restype = None
         r.getRenderStats.argtypes = [C.POINTER(render_stats)]
         r.getRenderStats.restype = None
         r.rtDeviceCount.argtypes = []
@@ -377,6 +380,17 @@ def setRenderOptions(opt=None, **kw):
             setattr(opt, k, v)
     load_renderer().setRenderOptions(C.byref(opt))
     return opt
+
+
+def setExternalFramebuffer(array):
+    """Deliver the following renders into `array` ((ny, nx, 3) float32, C-contiguous, e.g. a shared memmap); None reverts."""
+    if array is None:
+        load_renderer().setExternalFramebuffer(None)
+        _state["ext"] = None
+        return
+    assert array.dtype == np.float32 and array.flags["C_CONTIGUOUS"] and array.shape == (_state["ny"], _state["nx"], 3)
+    load_renderer().setExternalFramebuffer(array.ctypes.data)
+    _state["ext"] = array
 
 
 def getRenderStats():

@@ -76,6 +76,7 @@ struct RenderContext {
     rt_camera cam;
     rt_render_options opt;
     rt_vec3* h_fb = nullptr;            // pinned, nx*ny, handed to the caller
+    rt_vec3* h_ext = nullptr;           // caller-owned registered framebuffer (setExternalFramebuffer), or null
     // host copies of the scene (so devices can be (re)configured by setRenderOptions)
     std::vector<float4> h_spheres;      // padded
     std::vector<float4> h_mat_color;
@@ -328,6 +329,7 @@ void cleanup_impl() {
     RenderContext& c = g_ctx;
     for (DeviceState& d : c.devs) free_device(d);
     c.devs.clear();
+    if (c.h_ext) { HIP_CHECK(hipHostUnregister(c.h_ext)); c.h_ext = nullptr; }
     if (c.h_fb) HIP_CHECK(hipHostFree(c.h_fb));
     c = RenderContext();
 }
@@ -485,7 +487,7 @@ void runRenderer(int ns, int tx, int ty) {
         const int sr = c.opt.stripe_rows;
         const size_t stripe_bytes = (size_t)sr * row_bytes;
         const size_t full = d.fb_rows / sr, rem = d.fb_rows % sr;
-        char* dst0 = reinterpret_cast<char*>(c.h_fb) + (size_t)part.rank * stripe_bytes;
+        char* dst0 = reinterpret_cast<char*>(c.h_ext ? c.h_ext : c.h_fb) + (size_t)part.rank * stripe_bytes;
         const char* src0 = reinterpret_cast<const char*>(d.d_fb);
         if (full > 0)
             HIP_CHECK(hipMemcpy2DAsync(dst0, (size_t)world * stripe_bytes, src0, stripe_bytes, stripe_bytes, full,
@@ -526,6 +528,16 @@ void runRenderer(int ns, int tx, int ty) {
     st.samples = samples;
     st.num_launches = launches;
     c.stats = st;
+}
+
+void setExternalFramebuffer(rt_vec3* fb) {
+    RenderContext& c = g_ctx;
+    if (!c.initialised) rt_fail("setExternalFramebuffer before init");
+    if (c.h_ext) { HIP_CHECK(hipHostUnregister(c.h_ext)); c.h_ext = nullptr; }
+    if (fb) {
+        HIP_CHECK(hipHostRegister(fb, (size_t)c.nx * c.ny * sizeof(rt_vec3), hipHostRegisterDefault));
+        c.h_ext = fb;
+    }
 }
 
 void getRenderStats(rt_render_stats* out) {

@@ -39,9 +39,13 @@ class SharedFramebuffer:
         barrier()
         self.array = np.load(self.path, mmap_mode="r+")
 
-    def gather(self, fb, rows):
-        """Host-side gather of this rank's stripes (plain memcpy into the shared mapping)."""
-        self.array[rows] = fb[rows]
+    def gather(self, fb, rank, world, stripe=STRIPE_ROWS):
+        """Host-side gather of this rank's stripes: one contiguous memcpy per stripe into the shared mapping.
+        (With rt.setExternalFramebuffer(self.array) the renderer's device-to-host copies land here directly
+        and this call is not needed.)"""
+        ny = fb.shape[0]
+        for k in range(rank, (ny + stripe - 1) // stripe, world):
+            self.array[k * stripe:k * stripe + stripe] = fb[k * stripe:k * stripe + stripe]
 
     def close(self, barrier):
         barrier()

@@ -52,6 +52,12 @@ void getDefaultRenderOptions(rt_render_options* opt, int is_sphere_scene);
 /* Takes effect for the following runRenderer calls.  Call after init*. */
 void setRenderOptions(const rt_render_options* opt);
 
+/* Makes the following runRenderer calls deliver into caller-owned host memory (nx*ny vec3) instead of the
+ * library's own framebuffer: the buffer is page-locked with hipHostRegister and becomes the target of the
+ * device-to-host stripe copies.  Used for the multi-process host gather: every rank passes the same shared
+ * mapping and writes only the stripes it owns.  NULL switches back.  The caller keeps ownership. */
+void setExternalFramebuffer(rt_vec3* fb);
+
 /* Timing / counters of the last runRenderer. */
 void getRenderStats(rt_render_stats* out);
 

@@ -39,7 +39,7 @@ def _worker(rank, world, port, nx, ny, ns, out_path):
     opt = O.default_options(True)
     for k in range(rank, (ny + 7) // 8, world):                      # this rank's stripes only
         O.render(sc, cam, opt, nx, ny, ns, 50, region=(0, k * 8, nx, min(ny, k * 8 + 8)), fb=fb)
-    shared.gather(fb, rows)
+    shared.gather(fb, rank, world)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
