@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
 
 template <bool LEGACY>
 __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
-                                                                   int cull, int prio_after) {
+                                                                   int cull, int boost) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
     const SceneLds S = stage_scene(P, smem, &unused);
@@ -671,6 +671,8 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         return c % n;
     };
     const uint32_t stride0 = classified ? coprime_stride(n0) : 1u, stride1 = classified ? coprime_stride(n1) : 1u;
+    const uint32_t spread = gridDim.x * (uint32_t)kThreads;          // lanes in flight
+    const bool spread_ok = n0 > 0u && n0 <= spread && (spread - n0) <= n1;
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -679,13 +681,28 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     uint32_t nrays = 0, groups_done = 0;
     bool have_pixel = false;            // lane owns an unfinished pixel
     uint32_t pix_rays = 0;              // rays traced so far for the lane's current pixel
-    bool prio_raised = false;           // wave-uniform
     bool exhausted = false;             // wave-uniform: the global queue is empty
     float* fbf = reinterpret_cast<float*>(P.fb);
     // diagnostics (only when P.wave_dbg): 100 MHz time stamps and iteration counts of this wave
     const unsigned long long dbg_t0 = P.wave_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0;
+
+    // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
+    auto finish = [&](bool fin) {
+        if (fin) {
+            L.col = L.col + L.pcolor;                                // kernels.cu:558
+            L.s++;
+            if (L.s < P.ns) {
+                start_sample(P, L);
+            } else {
+                const f3 out = L.col / (float)P.ns;                  // kernels.cu:568
+                float* dst = fbf + ((size_t)lr * P.nx + L.i) * 3;
+                dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+                have_pixel = false;
+            }
+        }
+    };
 
     while (true) {
         // ---- refill idle lanes --------------------------------------------------------------------------------
@@ -707,8 +724,24 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 const uint32_t pos = base + rank;
                 uint32_t p;
                 if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
-                else if (pos < n0) p = P.order[(uint32_t)(((unsigned long long)pos * stride0) % n0)];
-                else if (pos < n0 + n1) p = P.order[padded + (uint32_t)(((unsigned long long)(pos - n0) * stride1) % n1)];
+                else if (pos < n0 + n1) {
+                    // classes 0 and 1: the n0 glass pixels are spread evenly over the first `spread` queue positions
+                    // (= the lanes in flight at t = 0), so every wave starts with a few of them instead of a few waves
+                    // with nothing else; position p is a class-0 position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
+                    uint32_t i0, i1;
+                    bool is0;
+                    if (spread_ok && pos < spread) {
+                        const uint32_t before = (uint32_t)(((unsigned long long)pos * n0) / spread);
+                        const uint32_t after = (uint32_t)(((unsigned long long)(pos + 1u) * n0) / spread);
+                        is0 = after > before; i0 = before; i1 = pos - before;
+                    } else if (spread_ok) {
+                        is0 = false; i0 = 0; i1 = pos - n0;
+                    } else {
+                        is0 = pos < n0; i0 = pos; i1 = pos - n0;
+                    }
+                    p = is0 ? P.order[(uint32_t)(((unsigned long long)i0 * stride0) % n0)]
+                            : P.order[padded + (uint32_t)(((unsigned long long)i1 * stride1) % n1)];
+                }
                 else p = P.order[2u * padded + (pos - n0 - n1)];
                 const uint32_t tile = p >> 6, within = p & 63u;
                 const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
@@ -726,33 +759,31 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         if (P.wave_dbg) {
             if (exhausted && dbg_tex == 0ull) dbg_tex = __builtin_amdgcn_s_memrealtime();
             dbg_iters++;
-            if (__popcll(live_now) < coop_below) { dbg_coop_iters++; dbg_coop_rays += (uint32_t)__popcll(live_now); }
-        }
-
-        // A pixel that has already needed many rays is one of the long sequential chains that decide when the frame
-        // ends (paths trapped in glass): the wave that holds one issues at raised priority, so the chain advances at
-        // close to single-wave speed while the SIMD's other waves fill the gaps.  Scheduling only: no effect on results.
-        if (prio_after > 0) {
-            const bool heavy = __ballot(have_pixel && pix_rays > (uint32_t)prio_after) != 0ull;
-            if (heavy != prio_raised) {
-                if (heavy) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-                prio_raised = heavy;
-            }
+            if (__popcll(live_now) <= kSparseRays) dbg_coop_iters++;     // iterations in sparse form
         }
 
         // ---- one ray per live lane ----------------------------------------------------------------------------
         if (have_pixel) { nrays++; pix_rays++; }
-        const bool done = trace_rays<LEGACY>(P, S, L, have_pixel, coop_below, cull != 0, groups_done);
-        if (have_pixel && done) {
-            L.col = L.col + L.pcolor;                                // kernels.cu:558
-            L.s++;
-            if (L.s < P.ns) {
-                start_sample(P, L);
-            } else {
-                const f3 out = L.col / (float)P.ns;                  // kernels.cu:568
-                float* dst = fbf + ((size_t)lr * P.nx + L.i) * 3;
-                dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
-                have_pixel = false;
+        bool done = trace_rays<LEGACY>(P, S, L, have_pixel, coop_below, cull != 0, groups_done);
+        finish(done && have_pixel);
+
+        // ---- boost the long chains ----------------------------------------------------------------------------------
+        // A pixel that keeps needing >= 10 rays per sample is one of the strictly sequential chains (paths trapped in
+        // glass) that decide when the frame ends.  While the wave is busy with 64 rays, such a lane would advance one ray
+        // per full iteration; give it `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
+        // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
+        if (!LEGACY && boost > 0 && __popcll(__ballot(have_pixel)) > kSparseRays) {
+            for (int x = 0; x < boost; x++) {
+                const bool heavy = have_pixel && pix_rays > 10u * (uint32_t)(L.s + 2);
+                const unsigned long long hm = __ballot(heavy);
+                if (hm == 0ull) break;
+                // at most kSparseRays of them per extra step
+                const uint32_t hr = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                const bool sel = heavy && hr < (uint32_t)kSparseRays;
+                if (sel) { nrays++; pix_rays++; }
+                if (P.wave_dbg) dbg_coop_rays += (uint32_t)__popcll(__ballot(sel));     // boost rays
+                done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done);
+                finish(done && sel);
             }
         }
     }
@@ -807,9 +838,9 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         if (e != hipSuccess) return e;
     }
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
-    // bits 27..29: raise the issue priority of waves that hold a pixel with more than 100 << (bits-1) rays (0 = off: measured no gain)
+    // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
     const int pb = (variant >> 27) & 7;
-    const int prio_after = (pb == 7 || pb == 0) ? 0 : (100 << (pb - 1));
+    const int boost = pb == 7 ? 0 : (pb == 0 ? 2 : pb);
     int coop_below = (variant >> 16) & 0xFF;
     if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
     if (coop_below == 255) coop_below = -2;    // pair-compacted scan only (A/B)
@@ -846,7 +877,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
-    if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, prio_after);
-    else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, prio_after);
+    if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, boost);
+    else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, boost);
     return hipGetLastError();
 }

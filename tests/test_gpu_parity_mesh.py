@@ -113,3 +113,18 @@ def test_mesh_textures_bit_exact(rt, O, stair):
     got = np.array(fb, copy=True)
     rt.cleanupRenderer()
     assert np.array_equal(_bits(got), _bits(ref))
+
+
+def test_mesh_stripe_partition_is_invisible(rt, stair):
+    """The multi-GPU stripe partition on the mesh path: three partition members rendered in turn on the one GPU,
+    interleaved, equal the whole frame bit for bit (NEE + RR on)."""
+    hm, mats = stair
+    nx, ny, ns = 64, 84, 2
+    cam = rt.staircase_camera(nx, ny)
+    whole, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 32)
+    merged = np.zeros_like(whole)
+    for r in range(3):
+        part, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 32, part_rank=r, part_world=3, stripe_rows=8)
+        for k in range(r, (ny + 7) // 8, 3):
+            merged[k * 8:(k + 1) * 8] = part[k * 8:(k + 1) * 8]
+    assert np.array_equal(_bits(merged), _bits(whole))

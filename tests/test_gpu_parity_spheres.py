@@ -225,3 +225,24 @@ def test_external_framebuffer(rt, O, tmp_path):
     rt.runRenderer(ns, 8, 8)
     assert np.array_equal(_bits(np.array(fb)), _bits(ref))
     rt.cleanupRenderer()
+
+
+def test_config5_image_size_crops(rt, O):
+    """BASELINE config-5 geometry (3840x2160, 488 spheres) at 1 spp on one GPU: the oracle checks four 24x16 crops,
+    and the frame must be complete (a pixel is black only when its single path ran into maxDepth inside glass:
+    a handful per frame; an unwritten stripe or tile would be thousands)."""
+    nx, ny, ns = 3840, 2160, 1
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50)
+    assert st.samples == nx * ny * ns
+    black = got.sum(axis=2) == 0
+    assert black.mean() < 1e-3, black.sum()
+    ys, xs = np.nonzero(black)
+    if len(ys):                      # and the oracle agrees that such a pixel is black
+        y, x = int(ys[0]), int(xs[0])
+        ref1, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50, region=(x, y, x + 1, y + 1))
+        assert not ref1[y, x].any()
+    sc = O.sphere_scene(sp, mt)
+    for (x0, y0) in ((0, 0), (1900, 1000), (3816, 2144), (2500, 700)):
+        ref, _ = O.render(sc, cam, O.default_options(True), nx, ny, ns, 50, region=(x0, y0, x0 + 24, y0 + 16))
+        assert np.array_equal(_bits(got[y0:y0 + 16, x0:x0 + 24]), _bits(ref[y0:y0 + 16, x0:x0 + 24])), (x0, y0)
