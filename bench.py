@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fp", choices=["parity", "fast"], default=os.environ.get("RT_BENCH_FP", "parity"))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("RT_BENCH_VARIANT", "0")))
+    ap.add_argument("--rng", choices=["reference", "counter"], default="reference",
+                    help="reference = the reference's per-pixel xorshift stream (the contract workload); counter = per-sample "
+                         "stream, samples split over lanes (a different, equally valid estimate of the same image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp", type=int, default=SPP, help="experiments only; the contract workload is 100")
     ap.add_argument("--max-depth", type=int, default=MAX_DEPTH, help="experiments only; the contract workload is 50")
@@ -98,7 +101,8 @@ def main():
     fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, MAX_DEPTH)
     opt = rt.getDefaultRenderOptions(True)
     fp = rt.RT_FP_FAST if args.fp == "fast" else rt.RT_FP_PARITY
-    rt.setRenderOptions(opt, fp=fp, variant=args.variant, part_rank=rank, part_world=world, stripe_rows=8)
+    rng_mode = rt.RT_RNG_COUNTER if args.rng == "counter" else rt.RT_RNG_REFERENCE_STREAM
+    rt.setRenderOptions(opt, fp=fp, rng=rng_mode, variant=args.variant, part_rank=rank, part_world=world, stripe_rows=8)
 
     # host gather target: one framebuffer shared by all ranks of the node
     shared = None
@@ -157,10 +161,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"random-spheres (488 spheres, LCG seed 0) {nx}x{ny} {SPP}spp maxDepth {MAX_DEPTH}, "
-                                   f"gradient sky, reference RNG stream, fp {args.fp}",
+                                   f"gradient sky, {args.rng} RNG stream, fp {args.fp}",
                        "image": [nx, ny], "spp": SPP, "max_depth": MAX_DEPTH, "spheres": N_SPHERES,
                        "partition": f"{world} x interleaved 8-row stripes, host gather" if world > 1 else "single GPU",
-                       "fp_mode": args.fp, "kernel_variant": args.variant},
+                       "fp_mode": args.fp, "rng": args.rng, "kernel_variant": args.variant},
             "frame_ms_kernel": kern_ms_max,
             "rays_per_sample": rays_total / total_samples,
             "executed_sphere_tests_per_ray_rank0": (exec_tests_local / rays_local) if rays_local else None,

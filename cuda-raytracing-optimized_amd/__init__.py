@@ -89,7 +89,8 @@ class render_options(C.Structure):
     _fields_ = [("sky", C.c_int32), ("nee", C.c_int32), ("rr", C.c_int32), ("t_min", C.c_float),
                 ("rng", C.c_int32), ("fp", C.c_int32), ("light", sphere), ("lightColor", vec3),
                 ("stripe_rows", C.c_int32), ("num_devices", C.c_int32), ("devices", C.c_int32 * RT_MAX_DEVICES),
-                ("part_rank", C.c_int32), ("part_world", C.c_int32), ("variant", C.c_int32), ("counters", C.c_int32)]
+                ("part_rank", C.c_int32), ("part_world", C.c_int32), ("variant", C.c_int32), ("counters", C.c_int32),
+                ("samples_per_item", C.c_int32)]
 
 
 class render_stats(C.Structure):

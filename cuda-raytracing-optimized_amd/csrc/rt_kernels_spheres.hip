@@ -147,12 +147,12 @@ __device__ __forceinline__ void start_sample(const RtSphereParams& P, Lane& L) {
     L.inside = false;
 }
 
-__device__ __forceinline__ void start_pixel(const RtSphereParams& P, Lane& L, int i, int j) {
+__device__ __forceinline__ void start_pixel(const RtSphereParams& P, Lane& L, int i, int j, int first_sample = 0) {
     L.i = i; L.j = j;
     L.pixelId = (uint32_t)(j * P.nx + i);                            // kernels.cu:541 (global id -> seed)
     L.rng = pixel_seed(L.pixelId);
     L.col = F3(0, 0, 0);
-    L.s = 0;
+    L.s = first_sample;
     start_sample(P, L);
 }
 
@@ -658,7 +658,9 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     // classified order: queue positions [0, n0) walk class 0 (glass), [n0, n0+n1) class 1, both in a scattered order,
     // then class 2 (sky) in list order
     const uint32_t n0 = classified ? P.queue[4] : 0u, n1 = classified ? P.queue[5] : 0u, n2 = classified ? P.queue[6] : 0u;
-    const uint32_t total = classified ? n0 + n1 + n2 : padded;
+    const uint32_t total_px = classified ? n0 + n1 + n2 : padded;
+    const uint32_t K = (uint32_t)P.chunks;                           // work items per pixel (1 unless RT_RNG_COUNTER)
+    const uint32_t total = total_px * K;
     auto coprime_stride = [](uint32_t n) {                           // ~0.618 n, coprime with n (wave-uniform)
         if (n <= 64u) return 1u;
         uint32_t c = ((uint32_t)((unsigned long long)n * 2654435769ull >> 32)) | 1u;
@@ -678,10 +680,12 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     L.col = F3(0, 0, 0);
     L.org = F3(0, 0, 0); L.dir = F3(0, 0, 1);
     int lr = 0;                         // local row of the lane's pixel (framebuffer row)
+    int chunk = 0, s_end = 0;           // the lane's work item: samples [chunk * spw, s_end) of its pixel
     uint32_t nrays = 0, groups_done = 0;
     bool have_pixel = false;            // lane owns an unfinished pixel
     uint32_t pix_rays = 0;              // rays traced so far for the lane's current pixel
     bool exhausted = false;             // wave-uniform: the global queue is empty
+    uint32_t pool_next = 0, pool_end = 0;   // wave-uniform: the wave's reserved queue positions [pool_next, pool_end)
     float* fbf = reinterpret_cast<float*>(P.fb);
     // diagnostics (only when P.wave_dbg): 100 MHz time stamps and iteration counts of this wave
     const unsigned long long dbg_t0 = P.wave_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -693,12 +697,17 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         if (fin) {
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
-            if (L.s < P.ns) {
+            if (L.s < s_end) {
                 start_sample(P, L);
             } else {
-                const f3 out = L.col / (float)P.ns;                  // kernels.cu:568
-                float* dst = fbf + ((size_t)lr * P.nx + L.i) * 3;
-                dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+                if (K == 1u) {
+                    const f3 out = L.col / (float)P.ns;              // kernels.cu:568
+                    float* dst = fbf + ((size_t)lr * P.nx + L.i) * 3;
+                    dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+                } else {                                             // partial sum of this chunk; k_sum_chunks adds them in order
+                    float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * K + (uint32_t)chunk) * 3;
+                    dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
+                }
                 have_pixel = false;
             }
         }
@@ -709,19 +718,31 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         while (!exhausted) {
             const unsigned long long need = __ballot(!have_pixel);
             if (need == 0ull) break;
-            // exactly as many pixels as there are idle lanes: nothing is hoarded in a wave while other waves idle
+            // Whole pixels (K == 1): reserve exactly as many as there are idle lanes, so nothing is hoarded in a wave while
+            // other waves idle.  Sample chunks (K > 1, counter RNG): items are small and plentiful, one atomic per idle
+            // lane-group would saturate the counter, so a wave reserves 128 at a time into a wave-local pool.
             const uint32_t cnt = (uint32_t)__popcll(need);
-            uint32_t base = 0;
-            if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue, cnt);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= total) { exhausted = true; break; }
+            if (pool_next >= pool_end) {
+                const uint32_t grab = (K > 1u) ? max(cnt, 128u) : cnt;
+                uint32_t b = 0;
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue, grab);
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (b >= total) { exhausted = true; break; }
+                pool_next = b;
+                pool_end = min(b + grab, total);
+            }
+            const uint32_t base = pool_next;
+            const uint32_t take = min(cnt, pool_end - pool_next);
+            pool_next += take;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (base + cnt >= total) exhausted = true;               // this grab took the last pixels
-            if (!have_pixel && base + rank < total) {
+            if (pool_next >= total) exhausted = true;                // this grab took the last items
+            if (!have_pixel && rank < take) {
                 // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
                 // neighbouring pixels over different waves, so the few very long pixels (paths trapped inside
                 // glass for 50 bounces, clustered on sphere rims) never share a wave; stride 1 = tile-major order
-                const uint32_t pos = base + rank;
+                const uint32_t item = base + rank;
+                const uint32_t pos = item / K;                       // position in the pixel order; the K chunks of a pixel are adjacent items
+                chunk = (int)(item - pos * K);
                 uint32_t p;
                 if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
                 else if (pos < n0 + n1) {
@@ -748,7 +769,8 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 const int i = tx * 8 + (int)(within & 7u);
                 lr = ty * 8 + (int)(within >> 3);
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
-                    start_pixel(P, L, i, global_row(P.part, lr));
+                    s_end = min(P.ns, (chunk + 1) * P.spw);
+                    start_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
                     have_pixel = true;
                     pix_rays = 0;
                 }
@@ -774,7 +796,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
         if (!LEGACY && boost > 0 && __popcll(__ballot(have_pixel)) > kSparseRays) {
             for (int x = 0; x < boost; x++) {
-                const bool heavy = have_pixel && pix_rays > 10u * (uint32_t)(L.s + 2);
+                const bool heavy = have_pixel && pix_rays > 10u * (uint32_t)(L.s - chunk * P.spw + 2);
                 const unsigned long long hm = __ballot(heavy);
                 if (hm == 0ull) break;
                 // at most kSparseRays of them per extra step
@@ -802,6 +824,20 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     }
 }
 
+}  // namespace
+
+// RT_RNG_COUNTER with chunks > 1: fb[pixel] = (chunk_0 + chunk_1 + ...) / ns, chunks added in index order (deterministic)
+namespace {
+__global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
+    const size_t px = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (px >= (size_t)P.part.local_rows * P.nx) return;
+    const float* src = reinterpret_cast<const float*>(P.partial) + px * P.chunks * 3;
+    f3 col = F3(src[0], src[1], src[2]);
+    for (int c = 1; c < P.chunks; c++) col = col + F3(src[3 * c], src[3 * c + 1], src[3 * c + 2]);
+    const f3 out = col / (float)P.ns;
+    float* dst = reinterpret_cast<float*>(P.fb) + px * 3;
+    dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+}
 }  // namespace
 
 static size_t lds_bytes(int n_padded, int n) {
@@ -879,5 +915,11 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     }
     if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, boost);
     else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, boost);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (p.chunks > 1) {
+        const size_t npx = (size_t)p.part.local_rows * p.nx;
+        hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }

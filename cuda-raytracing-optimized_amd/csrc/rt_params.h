@@ -50,6 +50,9 @@ struct RtSphereParams {
     uint32_t* queue;            // one zero-initialised word: next unassigned pixel (persistent-wave kernels)
     unsigned long long* wave_dbg;   // nullptr, or 8 x u64 per wave: diagnostic time stamps (RT_WAVE_DEBUG)
     uint32_t* order;            // 3 * padded pixel count words: work-order lists built by the classify pre-pass
+    int32_t spw;                // samples per work item (= ns in the reference-stream mode: one item per pixel)
+    int32_t chunks;             // work items per pixel = ceil(ns / spw)
+    rt_vec3* partial;           // chunks > 1: local_rows * nx * chunks un-normalised partial sums
 };
 
 struct RtMeshParams {

@@ -67,6 +67,8 @@ struct DeviceState {
     uint32_t* d_queue = nullptr;
     unsigned long long* d_wave_dbg = nullptr;
     uint32_t* d_order = nullptr;
+    rt_vec3* d_partial = nullptr;
+    size_t partial_bytes = 0;
 };
 
 struct RenderContext {
@@ -126,7 +128,7 @@ void free_device(DeviceState& d) {
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
-    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order);
+    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial);
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
     if (d.ev_stop) HIP_CHECK(hipEventDestroy(d.ev_stop));
     if (d.stream) HIP_CHECK(hipStreamDestroy(d.stream));
@@ -453,6 +455,22 @@ void runRenderer(int ns, int tx, int ty) {
             p.counters = c.opt.counters ? d.d_counters : nullptr;
             p.queue = d.d_queue;
             p.order = d.d_order;
+            // work items: one per pixel in the reference-stream mode (a pixel's samples are one sequential RNG stream);
+            // with the per-sample counter stream the samples are independent and a pixel is split into chunks
+            p.spw = ns; p.chunks = 1; p.partial = nullptr;
+            if (c.opt.rng == RT_RNG_COUNTER && (c.opt.variant & 0xFF) == 0) {
+                const int spw = c.opt.samples_per_item > 0 ? c.opt.samples_per_item : 4;
+                if (spw < ns) {
+                    p.spw = spw; p.chunks = (ns + spw - 1) / spw;
+                    const size_t need = d.fb_rows * c.nx * (size_t)p.chunks * sizeof(rt_vec3);
+                    if (need > d.partial_bytes) {
+                        if (d.d_partial) HIP_CHECK(hipFree(d.d_partial));
+                        HIP_CHECK(hipMalloc((void**)&d.d_partial, need));
+                        d.partial_bytes = need;
+                    }
+                    p.partial = d.d_partial;
+                }
+            }
             static const char* dbg_path = getenv("RT_WAVE_DEBUG");      // diagnostics: per-wave time stamps -> file
             const size_t dbg_bytes = (size_t)65536 * 8 * sizeof(unsigned long long);
             if (dbg_path) {

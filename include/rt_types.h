@@ -160,6 +160,8 @@ typedef struct rt_render_options {
     int32_t part_world;     /* 1 = whole image                                                 */
     int32_t variant;        /* kernel variant selector, 0 = default            */
     int32_t counters;       /* 1 = count rays / primitive tests / node visits (getRenderStats) */
+    int32_t samples_per_item; /* RT_RNG_COUNTER only: samples per work item (a pixel's samples are independent there and
+                               are split over lanes; partial sums are added in chunk order). 0 = default (4).    */
 } rt_render_options;
 
 typedef struct rt_render_stats {

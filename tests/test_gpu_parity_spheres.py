@@ -246,3 +246,22 @@ def test_config5_image_size_crops(rt, O):
     for (x0, y0) in ((0, 0), (1900, 1000), (3816, 2144), (2500, 700)):
         ref, _ = O.render(sc, cam, O.default_options(True), nx, ny, ns, 50, region=(x0, y0, x0 + 24, y0 + 16))
         assert np.array_equal(_bits(got[y0:y0 + 16, x0:x0 + 24]), _bits(ref[y0:y0 + 16, x0:x0 + 24])), (x0, y0)
+
+
+@pytest.mark.parametrize("spi", [0, 1, 3, 100])
+def test_counter_rng_sample_chunks(rt, O, spi):
+    """RT_RNG_COUNTER: one RNG stream per (pixel, sample), so a pixel's samples are independent work items and the
+    persistent kernel splits them into chunks of `samples_per_item` over different lanes.  Every sample is the oracle's
+    sample bit for bit; only the order of the final additions differs (chunk sums are added in chunk order instead of one
+    running sum): tolerance 2e-6 relative + 1e-7 absolute per channel (7 float additions of <= 1 ulp each)."""
+    nx, ny, ns = 128, 80, 7
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    o = O.default_options(True)
+    o.rng = rt.RT_RNG_COUNTER
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, o, nx, ny, ns, 50, counters=True)
+    got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, rng=rt.RT_RNG_COUNTER, samples_per_item=spi, counters=1)
+    assert st.rays == cnt.rays                     # the very same paths
+    if spi >= ns:
+        assert np.array_equal(_bits(got), _bits(ref))
+    else:
+        assert np.all(np.abs(got - ref) <= 2e-6 * np.abs(ref) + 1e-7)
