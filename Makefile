@@ -25,15 +25,15 @@ $(OBJ):
 $(OBJ)/spheres_parity.o: $(CSRC)/rt_kernels_spheres.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
 $(OBJ)/spheres_fast.o: $(CSRC)/rt_kernels_spheres.hip $(KERNEL_HDRS) | $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -c $< -o $@
 $(OBJ)/mesh_parity.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
 $(OBJ)/mesh_fast.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -c $< -o $@
 $(OBJ)/probe_parity.o: $(CSRC)/rt_probe.hip $(KERNEL_HDRS) include/rt_probe.h | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
 $(OBJ)/probe_fast.o: $(CSRC)/rt_probe.hip $(KERNEL_HDRS) include/rt_probe.h | $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -c $< -o $@
 $(OBJ)/renderer.o: $(CSRC)/rt_renderer.hip $(CSRC)/rt_params.h include/rt_api.h include/rt_types.h | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
