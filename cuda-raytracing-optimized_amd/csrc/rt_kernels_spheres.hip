@@ -327,8 +327,8 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 const float A = ro.w;
                 groups_done++;
                 uint32_t mask = 0;
-#pragma unroll
-                for (int kk = 0; kk < 16; kk++) {
+#pragma unroll 8
+                for (int kk = 0; kk < 16; kk++) {                    // 8 sphere loads in flight at a time keeps the kernel inside its VGPR budget
                     const float4 sph = S.sph[sbase + kk];
                     const float ocx = O.x - sph.x;
                     const float ocy = O.y - sph.y;
@@ -784,29 +784,26 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             if (__popcll(live_now) <= kSparseRays) dbg_coop_iters++;     // iterations in sparse form
         }
 
-        // ---- one ray per live lane ----------------------------------------------------------------------------
-        if (have_pixel) { nrays++; pix_rays++; }
-        bool done = trace_rays<LEGACY>(P, S, L, have_pixel, coop_below, cull != 0, groups_done);
-        finish(done && have_pixel);
-
-        // ---- boost the long chains ----------------------------------------------------------------------------------
+        // ---- one ray per live lane, then `boost` extra rays for the lanes on a long chain ---------------------------------
         // A pixel that keeps needing >= 10 rays per sample is one of the strictly sequential chains (paths trapped in
-        // glass) that decide when the frame ends.  While the wave is busy with 64 rays, such a lane would advance one ray
-        // per full iteration; give it `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
+        // glass) that decide when the frame ends.  While the wave is busy with 64 rays such a lane would advance one ray
+        // per full iteration; it gets `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
-        if (!LEGACY && boost > 0 && __popcll(__ballot(have_pixel)) > kSparseRays) {
-            for (int x = 0; x < boost; x++) {
+        // (One call site for both: the scan is large and must not be inlined twice.)
+        const int steps = (!LEGACY && boost > 0 && __popcll(live_now) > kSparseRays) ? 1 + boost : 1;
+        for (int x = 0; x < steps; x++) {
+            bool sel = have_pixel;
+            if (x > 0) {
                 const bool heavy = have_pixel && pix_rays > 10u * (uint32_t)(L.s - chunk * P.spw + 2);
                 const unsigned long long hm = __ballot(heavy);
                 if (hm == 0ull) break;
-                // at most kSparseRays of them per extra step
                 const uint32_t hr = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                const bool sel = heavy && hr < (uint32_t)kSparseRays;
-                if (sel) { nrays++; pix_rays++; }
-                if (P.wave_dbg) dbg_coop_rays += (uint32_t)__popcll(__ballot(sel));     // boost rays
-                done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done);
-                finish(done && sel);
+                sel = heavy && hr < (uint32_t)kSparseRays;           // at most kSparseRays of them per extra step
+                if (P.wave_dbg) dbg_coop_rays += (uint32_t)__popcll(__ballot(sel));
             }
+            if (sel) { nrays++; pix_rays++; }
+            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done);
+            finish(done && sel);
         }
     }
 
