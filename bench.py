@@ -36,6 +36,24 @@ FLOPS_PER_TEST = 18                 # sphereHit discriminant pat
 FLOPS_PER_RAY = 80                  # per-ray set-up + shading
 
 
+def measured_hbm_traffic():
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of THIS command
+    (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler around itself, so it reports the committed figure and
+    names its source; None if no summary is present."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_summary.txt")))
+    if not files:
+        return None, None
+    text = open(files[-1]).read()
+    f = re.search(r"^FETCH_SIZE\s+([0-9.e+]+)", text, re.M)
+    w = re.search(r"^WRITE_SIZE\s+([0-9.e+]+)", text, re.M)
+    if not (f and w):
+        return None, None
+    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(rt, nx, ny):
     """The reference's own header-only code as a single-threaded host loop (oracle/_ref), or our C
     restatement of it when the shim is absent, timed on a bounded sample of the SAME workload:
@@ -155,6 +173,7 @@ def main():
         rays_per_gpu = rays_total / world
         flops_per_launch = rays_per_gpu * (FLOPS_PER_TEST * N_SPHERES + FLOPS_PER_RAY)
         achieved = flops_per_launch / (kern_ms_max * 1e-3) / 1e12
+        traffic, traffic_src = measured_hbm_traffic() if (world == 1 and args.rng == "reference" and args.fp == "parity") else (None, None)
         out = {
             "metric": "Msamples/s (pixels x spp / s), random-spheres 1200x800x100spp",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,11 +188,14 @@ def main():
             "rays_per_sample": rays_total / total_samples,
             "executed_sphere_tests_per_ray_rank0": (exec_tests_local / rays_local) if rays_local else None,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "kernel": "k_render_spheres", "kernel_ms_avg": kern_ms_max,
                          "flops_per_launch": flops_per_launch,
-                         "note": "fp32 VALU bound (no MFMA, HBM traffic ~12 B/pixel/frame); algorithmic flops = "
-                                 "rays x (18 x 488 + 80), rays counted on the GPU (bit-equal to the oracle's count)"},
+                         "note": "fp32 VALU bound (no MFMA; algorithmic HBM bytes = 11.5 MB framebuffer per launch). achieved = "
+                                 "algorithmic flops of the reference's brute-force scan, rays x (18 x 488 + 80) with rays counted "
+                                 "on the GPU (bit-equal to the oracle's count), / kernel time; the kernel's exact group culling "
+                                 "executes only executed_sphere_tests_per_ray of the 488 tests per ray"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, nx, ny)
