@@ -47,7 +47,7 @@ namespace {
 constexpr int kWavesPerWg = 4;              // 4 waves side by side: a 32 x 8 pixel tile per workgroup
 constexpr int kThreads = 64 * kWavesPerWg;
 constexpr int kPassGroups = 16;                                  // groups per pair-list pass: at most 64 x 16 pairs
-constexpr int kWaveScratch = 64 * 32 + 64 * 8 + 64 * kPassGroups * 2;     // per wave: ray table, best-hit keys, (lane, group) pair list
+constexpr int kWaveScratch = 64 * 32 + 64 * 8 + (64 * kPassGroups + 64) * 2;     // per wave: ray table, best-hit keys, (lane, group) pair list
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     const int stripe = lr / pt.stripe_rows;
@@ -298,8 +298,13 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     // v_rcp_f32 (1 ulp) is enough here: the slab test is conservative by 1e-5 relative
     const f3 inv = F3(__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z));
 
+    // The pair list is filled pass by pass (kPassGroups groups at a time); only FULL rounds of 64 pairs are processed
+    // inside a pass, the remainder is carried to the front of the next pass's list, so a partial round runs once per
+    // ray batch instead of once per pass.  List entries hold the ABSOLUTE group index (8 bits) and the owner lane.
+    int carry = 0;                                                   // wave-uniform: pairs already in the list
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
         const int ng = min(kPassGroups, P.n_groups - g0);
+        const bool last_pass = g0 + kPassGroups >= P.n_groups;
         const uint32_t need = has_ray ? group_needs(S, g0, ng, org, inv, hb.closest, cull) : 0u;
         // exclusive prefix sum of the pair counts over the wave
         const int cnt = __popc(need);
@@ -309,18 +314,19 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             const int up = __shfl_up(incl, d, 64);
             if (lane >= d) incl += up;
         }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        int at = incl - cnt;
-        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 8) | __builtin_ctz(m));
+        const int total = carry + __builtin_amdgcn_readlane(incl, 63);
+        int at = carry + incl - cnt;
+        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 8) | (g0 + __builtin_ctz(m)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        for (int base = 0; base < total; base += 64) {
+        const int stop = last_pass ? total : (total & ~63);          // full rounds only, except in the last pass
+        for (int base = 0; base < stop; base += 64) {
             const int j = base + lane;
-            if (j < total) {
+            if (j < stop) {
                 const unsigned pr = w_pair[j];
                 const int owner = (int)(pr >> 8);
-                const int slot0 = (g0 + (int)(pr & 0xFFu)) << 4;
+                const int slot0 = (int)(pr & 0xFFu) << 4;
                 const int sbase = sidx(slot0);
                 const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
@@ -352,6 +358,13 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                     atomicMin(&w_best[owner], ((unsigned long long)__float_as_uint(h.closest) << 32) | (unsigned long long)(uint32_t)h.orig);
             }
         }
+        // carry the remainder to the front of the list
+        carry = total - stop;
+        unsigned short moved = 0;
+        if (lane < carry) moved = w_pair[stop + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < carry) w_pair[lane] = moved;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
