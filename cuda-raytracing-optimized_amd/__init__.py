@@ -27,6 +27,9 @@ RENDERER_LIB = os.path.join(_HERE, "librt_mi355x.so")
 HOST_LIB = os.path.join(_HERE, "librt_host.so")
 
 RT_DIFFUSE, RT_METAL, RT_GLASS = 0, 1, 2
+# additive: the reference's dormant look presets (scene_materials.h:22-93), see include/rt_types.h
+(RT_FLOOR_COAT, RT_FLOOR_DIFFUSE, RT_FLOOR_CHECKER, RT_MODEL_COAT, RT_MODEL_DIFFUSE, RT_MODEL_GLOSSY, RT_MODEL_GLASS,
+ RT_MODEL_TINTEDGLASS, RT_MODEL_SSS) = range(3, 12)
 RT_SKY_CONST_GREY, RT_SKY_GRADIENT = 0, 1
 RT_RNG_REFERENCE_STREAM, RT_RNG_COUNTER = 0, 1
 RT_FP_PARITY, RT_FP_FAST = 0, 1
@@ -503,12 +506,13 @@ class Probe:
         self._fn("Bbox")(_p(bmin), _p(bmax), _p(org), _p(dirs), _p(tmax), C.c_int(n), _p(dist), _p(hit))
         return dist, hit
 
-    def scatter(self, t, normal, inside, wo, mats, color, states):
+    def scatter(self, t, normal, inside, wo, mats, color, states, hit_point=None):
         t = _f32(t); normal = _f32(normal); inside = np.ascontiguousarray(inside, dtype=np.int32); wo = _f32(wo)
+        hp = _f32(hit_point if hit_point is not None else np.zeros((len(t), 3), np.float32))
         mats = np.ascontiguousarray(mats, dtype=material_dtype); color = _f32(color); st = _u32(states); n = len(t)
         wi = np.zeros((n, 3), np.float32); thr = np.zeros((n, 3), np.float32); flags = np.zeros(n, np.int32)
         tout = np.zeros(n, np.float32); sa = np.zeros(n, np.uint32)
-        self._fn("Scatter")(_p(t), _p(normal), _p(inside), _p(wo), _p(mats), _p(color), _p(st), C.c_int(n),
+        self._fn("Scatter")(_p(t), _p(hp), _p(normal), _p(inside), _p(wo), _p(mats), _p(color), _p(st), C.c_int(n),
                             _p(wi), _p(thr), _p(flags), _p(tout), _p(sa))
         return wi, thr, flags, tout, sa
 

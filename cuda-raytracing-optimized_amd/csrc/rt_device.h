@@ -130,46 +130,106 @@ struct Scatter {        // scatter_info, helper_structs.h:38-46
 
 // material_scatter, scene_materials.h:13-20, with the three BSDFs of material.h:27-31,46-53,55-60,73-92.
 // `normal` faces the ray; `inside` is the path's inside flag; `wo` the un-renormalised path direction.
-__device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 normal, bool inside, f3 wo,
+__device__ __forceinline__ f3 hex_color(int hexValue) {                    // scene_materials.h:6-11
+    const float r = (float)((hexValue >> 16) & 0xFF);
+    const float g = (float)((hexValue >> 8) & 0xFF);
+    const float b = (float)((hexValue) & 0xFF);
+    return F3(r, g, b) / 255.0f;
+}
+
+// fresnel_layer, material.h:55-60: true = the glossy (reflecting) layer is chosen; draws at most one random number
+__device__ __forceinline__ bool fresnel_layer(f3 normal, bool inside, f3 wo, float ior, uint32_t& rng) {
+    const float etai_over_etat = inside ? ior : (1.0f / ior);
+    const float cos_theta = fminf(dot(-wo, normal), 1.0f);
+    const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
+    bool r = etai_over_etat * sin_theta > 1.0f;
+    if (!r) r = rnd(rng) < schlick(cos_theta, etai_over_etat);
+    return r;
+}
+
+// material_scatter, scene_materials.h:13-20, with the BSDFs of material.h.  `normal` faces the ray; `inside` is the
+// path's inside flag; `wo` the un-renormalised path direction; `hp` the hit point (only the checker preset reads it).
+// type >= RT_FLOOR_COAT selects one of the reference's dormant look presets (scene_materials.h:22-93; additive).
+__device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 hp, f3 normal, bool inside, f3 wo,
                                                  int type, f3 color, float param, uint32_t& rng) {
-    // Throughput of every branch is either `color` or (1,1,1):
-    //   DIFFUSE  throughput = albedo                                   (material.h:29)
-    //   METAL    throughput = (1,1,1) * tint                           (material.h:51; 1*x == x exactly)
-    //   GLASS    throughput = exp(-0 * t) = (1,1,1) when inside        (material.h:77, absorption 0:
-    //            expf(-0.0f * t) == 1 for every finite t), then * tint only on the reflected branch (:80-82)
-    // so it is selected ONCE at the end from `refracted`.  (Written per branch as
-    // `out.throughput = out.throughput * color`, hipcc 7.2 dropped the x component of the product in
-    // the glass-reflect branch; tests/test_gpu_probe_functions.py::test_material_scatter pins this.)
-    (void)inside;
-    bool specular, refracted = false;
-    f3 v;                                            // un-normalised outgoing direction
-    if (type == RT_DIFFUSE) {
-        v = normal + random_in_unit_sphere(rng);     // material.h:28
+    // Every branch is reduced to: an un-normalised outgoing direction v (normalised once at the end, except for the
+    // subsurface scattering event which the reference leaves un-normalised, material.h:128), a throughput, flags and t.
+    // (Written per branch as `out.throughput = out.throughput * color`, hipcc 7.2 dropped the x component of the
+    // product in the glass-reflect branch; tests/test_gpu_probe_functions.py::test_material_scatter pins this.)
+    bool specular = true, refracted = false, normalise = true;
+    f3 v;
+    f3 thr = F3(1.0f, 1.0f, 1.0f);
+    float t_out = hit_t;
+
+    // ---- which BSDF, with which parameters
+    enum { B_DIFFUSE, B_GLOSSY, B_COAT, B_DIELECTRIC, B_SSS } bsdf;
+    f3 albedo = color;                  // diffuse albedo
+    f3 tint = color;                    // glossy / dielectric tint
+    float ior = param, fuzz = 0.0f;
+    f3 absorption = F3(0, 0, 0);
+    const f3 model_base = F3(0.0972942f, 0.0482054f, 0.000273194f);
+    switch (type) {
+    case RT_DIFFUSE: bsdf = B_DIFFUSE; break;
+    case RT_METAL:   bsdf = B_GLOSSY; fuzz = param; break;
+    case RT_GLASS:   bsdf = B_DIELECTRIC; break;                                 // tint = color, absorption 0
+    case RT_FLOOR_COAT:    bsdf = B_COAT; ior = 1.5f; albedo = hex_color(0x511845); tint = F3(1, 1, 1); break;
+    case RT_FLOOR_DIFFUSE: bsdf = B_DIFFUSE; albedo = hex_color(0x511845); break;
+    case RT_FLOOR_CHECKER: {                                                     // checker_layer, material.h:33-36
+        const float sines = sinf(0.2f * hp.x) * sinf(0.2f * hp.y) * sinf(0.2f * hp.z);
+        bsdf = B_DIFFUSE; albedo = (sines < 0) ? hex_color(0x511845) : hex_color(0xff5733);
+        break;
+    }
+    case RT_MODEL_COAT:    bsdf = B_COAT; ior = 1.1f; albedo = model_base; tint = F3(1, 1, 1); break;
+    case RT_MODEL_DIFFUSE: bsdf = B_DIFFUSE; albedo = model_base; break;
+    case RT_MODEL_GLOSSY:  bsdf = B_GLOSSY; tint = F3(1, 1, 1); break;
+    case RT_MODEL_GLASS:   bsdf = B_DIELECTRIC; ior = 1.1f; tint = F3(1, 1, 1); break;
+    case RT_MODEL_TINTEDGLASS:
+        bsdf = B_DIELECTRIC; ior = 1.1f; tint = F3(1, 1, 1);
+        absorption = (-F3(logf(model_base.x), logf(model_base.y), logf(model_base.z))) / 10.0f;
+        break;
+    default:               bsdf = B_SSS; ior = 1.333f; tint = F3(1, 1, 1); absorption = F3(0.9f, 0.3f, 0.02f); break;
+    }
+
+    if (bsdf == B_COAT) bsdf = fresnel_layer(normal, inside, wo, ior, rng) ? B_GLOSSY : B_DIFFUSE;     // material.h:62-70
+
+    if (bsdf == B_DIFFUSE) {                                 // diffuse_bsdf, material.h:27-31
+        v = normal + random_in_unit_sphere(rng);
+        thr = albedo;
         specular = false;
-    } else if (type == RT_METAL) {
-        v = reflect(wo, normal);                     // material.h:47-50
-        if (param > 0.0001f) v = v + param * random_in_unit_sphere(rng);
-        specular = true;
+    } else if (bsdf == B_GLOSSY) {                           // glossy_bsdf, material.h:46-53 (throughput 1 * tint == tint)
+        v = reflect(wo, normal);
+        if (fuzz > 0.0001f) v = v + fuzz * random_in_unit_sphere(rng);
+        thr = tint;
     } else {
-        // dielectric_bsdf(ior = param, tint = color, fuzz 0, absorption 0), material.h:73-92 + fresnel_layer :55-60
-        const float etai_over_etat = inside ? param : (1.0f / param);
-        const float cos_theta = fminf(dot(-wo, normal), 1.0f);
-        const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
-        bool reflect_it = etai_over_etat * sin_theta > 1.0f;
-        if (!reflect_it) reflect_it = rnd(rng) < schlick(cos_theta, etai_over_etat);
-        if (reflect_it) {
-            v = reflect(wo, normal);                 // glossy_bsdf with fuzz 0
+        // dielectric_bsdf (material.h:73-92) / subsurface_dielectric_bsdf (:119-143)
+        bool scattered = false;
+        if (inside) {
+            if (bsdf == B_SSS) {
+                const float d = -logf(rnd(rng)) / 2.0f;      // scatteringDistance 2.0 (scene_materials.h:91)
+                if (d < hit_t) { scattered = true; t_out = d; }
+            }
+            // exp(-absorption * t) (material.h:77,126); with absorption == 0 that is expf(-0.0f * t) == 1 exactly
+            if (absorption.x != 0.0f || absorption.y != 0.0f || absorption.z != 0.0f) {
+                const f3 e = t_out * (-absorption);
+                thr = F3(expf(e.x), expf(e.y), expf(e.z));
+            }
+        }
+        if (scattered) {
+            v = random_in_unit_sphere(rng);
+            normalise = false;                               // material.h:128: wi is NOT normalised
+        } else if (fresnel_layer(normal, inside, wo, ior, rng)) {
+            v = reflect(wo, normal);                         // glossy_bsdf, fuzz 0
+            thr = thr * tint;
         } else {
-            v = refract(wo, normal, etai_over_etat);
+            v = refract(wo, normal, inside ? ior : (1.0f / ior));
             refracted = true;
         }
-        specular = true;
     }
-    out.wi = unit(v);
-    out.throughput = refracted ? F3(1.0f, 1.0f, 1.0f) : color;
+    out.wi = normalise ? unit(v) : v;
+    out.throughput = thr;
     out.specular = specular;
     out.refracted = refracted;
-    out.t = hit_t;
+    out.t = t_out;
 }
 
 // Sky, kernels.cu:419-421 (gradient) / :424 (constant grey)

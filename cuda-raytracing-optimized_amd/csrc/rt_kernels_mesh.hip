@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) 
                 albedo = ld3(mat.color);
             }
             Scatter sc;
-            material_scatter(sc, t, normal, inside, dir, mat.type, albedo, mat.param, rng);
+            material_scatter(sc, t, r.o + t * r.d, normal, inside, dir, mat.type, albedo, mat.param, rng);
             org = org + sc.t * dir;                                  // kernels.cu:485-489
             dir = sc.wi;
             atten = atten * sc.throughput;
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
                         albedo = ld3(mat.color);
                     }
                     Scatter sc;
-                    material_scatter(sc, t, normal, inside, dir, mat.type, albedo, mat.param, rng);
+                    material_scatter(sc, t, J.r.o + t * J.r.d, normal, inside, dir, mat.type, albedo, mat.param, rng);
                     org = org + sc.t * dir;                          // kernels.cu:485-489
                     dir = sc.wi;
                     atten = atten * sc.throughput;

@@ -482,7 +482,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
     if (dot(dn, normal) > 0.0f) normal = -normal;                    // kernels.cu:354-355
     const float4 m = S.mat[h.sid];
     Scatter sc;
-    material_scatter(sc, h.closest, normal, L.inside, L.dir, S.typ[h.sid], F3(m.x, m.y, m.z), m.w, L.rng);
+    material_scatter(sc, h.closest, hp, normal, L.inside, L.dir, S.typ[h.sid], F3(m.x, m.y, m.z), m.w, L.rng);
     L.org = L.org + sc.t * L.dir;                                    // kernels.cu:485-489
     L.dir = sc.wi;
     L.atten = L.atten * sc.throughput;

@@ -116,7 +116,7 @@ __global__ void k_bbox(const float* bmin, const float* bmax, const float* org, c
     hit_out[k] = hit_bbox(ld(bmin, k), ld(bmax, k), r, tmax[k]) ? 1 : 0;
 }
 
-__global__ void k_scatter(const float* t, const float* normal, const int* inside, const float* wo, const rt_material* mats,
+__global__ void k_scatter(const float* t, const float* hp, const float* normal, const int* inside, const float* wo, const rt_material* mats,
                           const float* color, const uint32_t* states, int n,
                           float* wi, float* throughput, int* flags, float* t_out, uint32_t* st_after) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,7 +124,7 @@ __global__ void k_scatter(const float* t, const float* normal, const int* inside
     uint32_t st = states[k];
     Scatter sc;
     sc.wi = F3(0, 0, 0);
-    material_scatter(sc, t[k], ld(normal, k), inside[k] != 0, ld(wo, k), mats[k].type, ld(color, k), mats[k].param, st);
+    material_scatter(sc, t[k], ld(hp, k), ld(normal, k), inside[k] != 0, ld(wo, k), mats[k].type, ld(color, k), mats[k].param, st);
     stv(wi, k, sc.wi);
     stv(throughput, k, sc.throughput);
     flags[k] = (sc.specular ? 1 : 0) | (sc.refracted ? 2 : 0);
@@ -190,14 +190,14 @@ void PROBE(rtProbeBbox)(const float* bmin3, const float* bmax3, const float* org
     sync();
 }
 
-void PROBE(rtProbeScatter)(const float* t, const float* normal3, const int* inside, const float* wo3, const rt_material* mats,
+void PROBE(rtProbeScatter)(const float* t, const float* p3, const float* normal3, const int* inside, const float* wo3, const rt_material* mats,
                            const float* color3, const uint32_t* states, int n,
                            float* wi3, float* throughput3, int* flags, float* t_out, uint32_t* st_after) {
-    auto a = in(t, n); auto b = in(normal3, (size_t)3 * n); auto c = in(inside, n); auto d = in(wo3, (size_t)3 * n);
+    auto a = in(t, n); auto pp = in(p3, (size_t)3 * n); auto b = in(normal3, (size_t)3 * n); auto c = in(inside, n); auto d = in(wo3, (size_t)3 * n);
     auto e = in(mats, n); auto f = in(color3, (size_t)3 * n); auto g = in(states, n);
     auto h = outb(wi3, (size_t)3 * n); auto i = outb(throughput3, (size_t)3 * n); auto j = outb(flags, n);
     auto k = outb(t_out, n); auto l = outb(st_after, n);
-    hipLaunchKernelGGL(k_scatter, grid_for(n), dim3(256), 0, 0, a.d, b.d, c.d, d.d, e.d, f.d, g.d, n, h.d, i.d, j.d, k.d, l.d);
+    hipLaunchKernelGGL(k_scatter, grid_for(n), dim3(256), 0, 0, a.d, pp.d, b.d, c.d, d.d, e.d, f.d, g.d, n, h.d, i.d, j.d, k.d, l.d);
     sync();
 }
 

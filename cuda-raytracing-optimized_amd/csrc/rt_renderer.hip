@@ -396,7 +396,7 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
     c.is_spheres = true;
     default_options(&c.opt, 1);
     for (int k = 0; k < n; k++)
-        if (materials[k].type < RT_DIFFUSE || materials[k].type > RT_GLASS) rt_fail("initRendererSpheres: bad material type");
+        if (materials[k].type < RT_DIFFUSE || materials[k].type >= RT_MATERIAL_TYPE_COUNT) rt_fail("initRendererSpheres: bad material type");
     build_sphere_groups(spheres, materials, n);
     if (rt_sphere_kernel_lds_bytes(c.n_padded, n, 256) > 160 * 1024)
         rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 3500 spheres)");

@@ -15,7 +15,7 @@
  *   rtProbeSphereHit    sphereHit                             intersections.h:85-104
  *   rtProbeTriangleHit  triangleHit                           intersections.h:54-83
  *   rtProbeBbox         hit_bbox_dist, hit_bbox               intersections.h:7-41
- *   rtProbeScatter      material_scatter (3 BSDFs)            scene_materials.h:13-20; material.h:9-92
+ *   rtProbeScatter      material_scatter (3 BSDFs + presets)  scene_materials.h:13-93; material.h:9-143 (p3 = hit point)
  *   rtProbeMath         a/b, sqrt|a|, pow(a,5), unit_vector   vec3.h:79-81,35,194-196; material.h:12
  */
 #ifndef RT_PROBE_H
@@ -39,7 +39,7 @@ void rtProbeTriangleHit##sfx(const rt_triangle* tris, const float* org3, const f
 void rtProbeBbox##sfx(const float* bmin3, const float* bmax3, const float* org3, const float* dir3, const float* tmax, \
                       int n, float* dist_out, int* hit_out); \
 /* flags: bit0 = specular, bit1 = refracted */ \
-void rtProbeScatter##sfx(const float* t, const float* normal3, const int* inside, const float* wo3, const rt_material* mats, \
+void rtProbeScatter##sfx(const float* t, const float* p3, const float* normal3, const int* inside, const float* wo3, const rt_material* mats, \
                          const float* color3, const uint32_t* states, int n, \
                          float* wi3, float* throughput3, int* flags, float* t_out, uint32_t* st_after); \
 void rtProbeMath##sfx(const float* a, const float* b, int n, float* quot, float* root, float* p5, float* unit3);

@@ -63,7 +63,19 @@ typedef struct rt_triangle {
 typedef struct rt_bvh_node { rt_vec3 a; rt_vec3 b; } rt_bvh_node;
 
 /* material_type, helper_structs.h:127-131 */
-enum { RT_DIFFUSE = 0, RT_METAL = 1, RT_GLASS = 2 };
+enum { RT_DIFFUSE = 0, RT_METAL = 1, RT_GLASS = 2,
+       /* Additive: the reference's dormant look presets, scene_materials.h:22-93 — hard-coded
+        * parameters, reachable from no scene at HEAD; material.color / param are ignored for them. */
+       RT_FLOOR_COAT = 3,        /* floor_coat_scatter        :22-28  coat_bsdf(ior 1.5, base 0x511845)            */
+       RT_FLOOR_DIFFUSE = 4,     /* floor_diffuse_scatter     :30-33                                               */
+       RT_FLOOR_CHECKER = 5,     /* floor_checker_scatter     :35-44  checker_layer(0.2) 0x511845 / 0xff5733       */
+       RT_MODEL_COAT = 6,        /* model_coat_scatter        :46-52  coat_bsdf(ior 1.1)                           */
+       RT_MODEL_DIFFUSE = 7,     /* model_diffuse_scatter     :54-57                                               */
+       RT_MODEL_GLOSSY = 8,      /* model_glossy_scatter      :59-63                                               */
+       RT_MODEL_GLASS = 9,       /* model_glass_scatter       :65-71  dielectric ior 1.1                           */
+       RT_MODEL_TINTEDGLASS = 10,/* model_tintedglass_scatter :73-81  Beer-Lambert absorption                      */
+       RT_MODEL_SSS = 11,        /* model_sss_scatter         :83-93  subsurface_dielectric_bsdf                   */
+       RT_MATERIAL_TYPE_COUNT = 12 };
 
 typedef struct rt_material {
     int32_t type;       /* RT_DIFFUSE / RT_METAL / RT_GLASS */

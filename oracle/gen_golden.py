@@ -157,6 +157,26 @@ def main():
                         wi=wi, throughput=thr, flags=flags, t_out=tout, st_out=sta,
                         cos=cosv, idx=idx, schlick=schl, reflect=refl, refract=refr, srgb_in=srgb_in, srgb=srgb)
 
+    # ---- dormant look presets (scene_materials.h:22-93), called through the reference's own preset functions -----------
+    M = 540
+    pn = rng.normal(size=(M, 3)); pn /= np.linalg.norm(pn, axis=1)[:, None]
+    pw = rng.normal(size=(M, 3)); pw /= np.linalg.norm(pw, axis=1)[:, None]
+    fl = (pw * pn).sum(1) > 0; pn[fl] *= -1
+    pn = pn.astype(np.float32); pw = pw.astype(np.float32)
+    pp = rng.uniform(-30, 30, (M, 3)).astype(np.float32)
+    pt = rng.uniform(0.01, 6, M).astype(np.float32)
+    pin = (rng.uniform(size=M) < 0.5).astype(np.int32)
+    pkind = (3 + np.arange(M) % 9).astype(np.int32)
+    pst = (rng.integers(1, 2 ** 32, M, dtype=np.uint64).astype(np.uint32)) | 1
+    pwi = np.zeros((M, 3), np.float32); pthr = np.zeros((M, 3), np.float32); pfl = np.zeros(M, np.int32)
+    pto = np.zeros(M, np.float32); psa = np.zeros(M, np.uint32)
+    for k in range(M):
+        st = C.c_uint32(int(pst[k]))
+        ref.ref_preset_scatter(int(pkind[k]), float(pt[k]), f3(pp[k]), f3(pn[k]), int(pin[k]), f3(pw[k]), C.byref(st), C.byref(sc))
+        pwi[k] = sc.wi[:]; pthr[k] = sc.throughput[:]; pfl[k] = sc.specular | (sc.refracted << 1); pto[k] = sc.t; psa[k] = st.value
+    np.savez_compressed(os.path.join(OUT, "presets.npz"), kind=pkind, t=pt, p=pp, normal=pn, inside=pin, wo=pw, st_in=pst,
+                        wi=pwi, throughput=pthr, flags=pfl, t_out=pto, st_out=psa)
+
     # ---- light-sampling expression probes (kernels.cu:378-387) -------------------------------------------------------
     M = 200
     su = rng.normal(size=(M, 3)).astype(np.float32); sv = rng.normal(size=(M, 3)).astype(np.float32); sw = rng.normal(size=(M, 3)).astype(np.float32)

@@ -61,6 +61,12 @@ def _bind_common(lib, pre):
     g("material_scatter").argtypes = [C.c_float, _fp, C.c_int, _fp, C.POINTER(rt.material), _fp, _u32p, C.POINTER(orc_scatter)]
     g("material_scatter").restype = None
     g("linear_to_srgb").argtypes = [C.c_float]; g("linear_to_srgb").restype = C.c_uint32
+    if pre == "orc_":
+        lib.orc_material_scatter_p.argtypes = [C.c_float, _fp, _fp, C.c_int, _fp, C.POINTER(rt.material), _fp, _u32p, C.POINTER(orc_scatter)]
+        lib.orc_material_scatter_p.restype = None
+    else:
+        lib.ref_preset_scatter.argtypes = [C.c_int, C.c_float, _fp, _fp, C.c_int, _fp, _u32p, C.POINTER(orc_scatter)]
+        lib.ref_preset_scatter.restype = None
 
 
 _oracle = None

@@ -133,6 +133,27 @@ void ref_material_scatter(float inters_t, const float normal[3], int inside, con
     out->refracted = sc.refracted; out->t = sc.t;
 }
 
+/* The dormant look presets, called exactly as scene_materials.h:22-93 defines them. kind = RT_FLOOR_COAT .. RT_MODEL_SSS */
+void ref_preset_scatter(int kind, float inters_t, const float p[3], const float normal[3], int inside, const float wo[3],
+                        uint32_t* rng, orc_scatter* out) {
+    intersection in; memset((void*)&in, 0, sizeof in);
+    in.t = inters_t; in.p = V(p); in.normal = V(normal); in.inside = inside != 0;
+    scatter_info sc(in);
+    switch (kind) {
+    case RT_FLOOR_COAT:        floor_coat_scatter(sc, in, V(wo), *rng); break;
+    case RT_FLOOR_DIFFUSE:     floor_diffuse_scatter(sc, in, V(wo), *rng); break;
+    case RT_FLOOR_CHECKER:     floor_checker_scatter(sc, in, V(wo), *rng); break;
+    case RT_MODEL_COAT:        model_coat_scatter(sc, in, V(wo), *rng); break;
+    case RT_MODEL_DIFFUSE:     model_diffuse_scatter(sc, in, V(wo), *rng); break;
+    case RT_MODEL_GLOSSY:      model_glossy_scatter(sc, in, V(wo), *rng); break;
+    case RT_MODEL_GLASS:       model_glass_scatter(sc, in, V(wo), *rng); break;
+    case RT_MODEL_TINTEDGLASS: model_tintedglass_scatter(sc, in, V(wo), *rng); break;
+    default:                   model_sss_scatter(sc, in, V(wo), *rng); break;
+    }
+    S(out->wi, sc.wi); out->specular = sc.specular; S(out->throughput, sc.throughput);
+    out->refracted = sc.refracted; out->t = sc.t;
+}
+
 uint32_t ref_linear_to_srgb(float x) { return LinearToSRGB(x); }
 
 /* Expression probes: the two vec3 expressions of generateShadowRay whose operator order matters

@@ -314,8 +314,75 @@ static void dielectric_bsdf(scat_t* out, const inters_t* i, v3 wo, float layer_i
     out->specular = 1;
 }
 
+static int checker_layer(const inters_t* i, float frequency) {     /* material.h:33-36 */
+    float sines = sinf(frequency * i->p.x) * sinf(frequency * i->p.y) * sinf(frequency * i->p.z);
+    return sines < 0;
+}
+
+static void coat_bsdf(scat_t* out, const inters_t* i, v3 wo, float layer_ior, v3 glossy_tint, float glossy_fuzz, v3 diffuse_albedo,
+                      uint32_t* rng) {                                /* material.h:62-70 */
+    if (fresnel_layer(i, wo, layer_ior, rng)) glossy_bsdf(out, i, wo, glossy_tint, glossy_fuzz, rng);
+    else diffuse_bsdf(out, i, diffuse_albedo, rng);
+}
+
+static void subsurface_dielectric_bsdf(scat_t* out, const inters_t* i, v3 wo, float layer_ior, v3 glossy_tint, float glossy_fuzz,
+                                       v3 absorption, float scatteringDistance, uint32_t* rng) {    /* material.h:119-143 */
+    int scattered = 0;
+    if (i->inside) {
+        float d = -logf(rnd(rng)) / scatteringDistance;
+        if (d < i->t) { scattered = 1; out->t = d; }
+        v3 e = muls(out->t, neg(absorption));
+        out->throughput = V(expf(e.x), expf(e.y), expf(e.z));
+    }
+    if (scattered) {
+        out->wi = random_in_unit_sphere(rng);            /* not normalised in the reference (:128) */
+    } else {
+        if (fresnel_layer(i, wo, layer_ior, rng)) {
+            glossy_bsdf(out, i, wo, glossy_tint, glossy_fuzz, rng);
+        } else {
+            float etai_over_etat = i->inside ? layer_ior : (1.0f / layer_ior);
+            out->wi = unit(refract_(wo, i->normal, etai_over_etat));
+            out->refracted = 1;
+        }
+    }
+    out->specular = 1;
+}
+
+static v3 hex_color(int hexValue) {                     /* scene_materials.h:6-11 */
+    float r = (float)((hexValue >> 16) & 0xFF);
+    float g = (float)((hexValue >> 8) & 0xFF);
+    float b = (float)((hexValue) & 0xFF);
+    return divs(V(r, g, b), 255.0f);
+}
+
+/* the dormant look presets, scene_materials.h:22-93 */
+static void preset_scatter(scat_t* out, const inters_t* i, v3 wo, int type, uint32_t* rng) {
+    const v3 one = V(1, 1, 1);
+    const v3 model_base = V(0.0972942f, 0.0482054f, 0.000273194f);
+    switch (type) {
+    case RT_FLOOR_COAT:    coat_bsdf(out, i, wo, 1.5f, one, 0.0f, hex_color(0x511845), rng); break;
+    case RT_FLOOR_DIFFUSE: diffuse_bsdf(out, i, hex_color(0x511845), rng); break;
+    case RT_FLOOR_CHECKER:
+        if (checker_layer(i, 0.2f)) diffuse_bsdf(out, i, hex_color(0x511845), rng);
+        else diffuse_bsdf(out, i, hex_color(0xff5733), rng);
+        break;
+    case RT_MODEL_COAT:    coat_bsdf(out, i, wo, 1.1f, one, 0.0f, model_base, rng); break;
+    case RT_MODEL_DIFFUSE: diffuse_bsdf(out, i, model_base, rng); break;
+    case RT_MODEL_GLOSSY:  glossy_bsdf(out, i, wo, one, 0.0f, rng); break;
+    case RT_MODEL_GLASS:   dielectric_bsdf(out, i, wo, 1.1f, one, 0.0f, V(0, 0, 0), rng); break;
+    case RT_MODEL_TINTEDGLASS: {
+        const float absorptionDistance = 10;
+        const v3 absorption = divs(neg(V(logf(model_base.x), logf(model_base.y), logf(model_base.z))), absorptionDistance);
+        dielectric_bsdf(out, i, wo, 1.1f, one, 0.0f, absorption, rng);
+        break;
+    }
+    default:               subsurface_dielectric_bsdf(out, i, wo, 1.333f, one, 0.0f, V(0.9f, 0.3f, 0.02f), 2.0f, rng); break;
+    }
+}
+
 static void material_scatter(scat_t* out, const inters_t* i, v3 wo, const rt_material* mat, v3 color, uint32_t* rng) {
     /* scene_materials.h:13-20 */
+    if (mat->type >= RT_FLOOR_COAT) { preset_scatter(out, i, wo, mat->type, rng); return; }
     if (mat->type == RT_DIFFUSE)
         diffuse_bsdf(out, i, color, rng);
     else if (mat->type == RT_METAL)
@@ -329,6 +396,16 @@ static inline scat_t scat_init(const inters_t* i) {     /* helper_structs.h:45 *
     s.wi = V(0, 0, 0);
     s.specular = 0; s.throughput = V(1, 1, 1); s.refracted = 0; s.t = i->t;
     return s;
+}
+
+void orc_material_scatter_p(float inters_t_, const float p[3], const float normal[3], int inside, const float wo[3],
+                            const rt_material* mat, const float color[3], uint32_t* rng, orc_scatter* out) {
+    inters_t i; memset(&i, 0, sizeof i);
+    i.t = inters_t_; i.p = ld(p); i.normal = ld(normal); i.inside = inside;
+    scat_t s = scat_init(&i);
+    material_scatter(&s, &i, ld(wo), mat, ld(color), rng);
+    st(out->wi, s.wi); out->specular = s.specular; st(out->throughput, s.throughput);
+    out->refracted = s.refracted; out->t = s.t;
 }
 
 void orc_material_scatter(float inters_t_, const float normal[3], int inside, const float wo[3],

@@ -89,6 +89,10 @@ typedef struct orc_scatter {    /* scatter_info, helper_structs.h:38-46 */
 void orc_material_scatter(float inters_t, const float normal[3], int inside, const float wo[3],
                           const rt_material* mat, const float color[3], uint32_t* rng, orc_scatter* out);
 
+/* same with the hit point p (the checker preset reads it, material.h:33-36); mat->type may be a preset (RT_FLOOR_COAT ...) */
+void orc_material_scatter_p(float inters_t, const float p[3], const float normal[3], int inside, const float wo[3],
+                            const rt_material* mat, const float color[3], uint32_t* rng, orc_scatter* out);
+
 /* kernels.cu:154-224; returns closest t (or t_max); *tri_id,*u,*v valid when result < t_max */
 float orc_hit_bvh(const orc_scene* sc, const float org[3], const float dir_in[3], float t_min, float t_max,
                   int is_shadow, uint32_t* tri_id, float* u, float* v, orc_counters* cnt);

@@ -265,3 +265,26 @@ def test_counter_rng_sample_chunks(rt, O, spi):
         assert np.array_equal(_bits(got), _bits(ref))
     else:
         assert np.all(np.abs(got - ref) <= 2e-6 * np.abs(ref) + 1e-7)
+
+
+def test_preset_materials_in_a_frame(rt, O):
+    """The dormant presets as sphere materials in a whole frame.  Presets without libm calls: bit-exact frame.
+    With checker / tinted glass / subsurface spheres: >= 99.5 % of channels within 1e-5 relative (OCML vs glibc ulps)."""
+    nx, ny, ns = 128, 80, 4
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    small = np.arange(1, 485)
+    exact_kinds = np.array([rt.RT_FLOOR_COAT, rt.RT_FLOOR_DIFFUSE, rt.RT_MODEL_COAT, rt.RT_MODEL_DIFFUSE, rt.RT_MODEL_GLOSSY, rt.RT_MODEL_GLASS])
+    m1 = mt.copy()
+    m1["type"][small] = exact_kinds[small % len(exact_kinds)]
+    m1["type"][485] = rt.RT_MODEL_GLASS
+    ref, _ = O.render(O.sphere_scene(sp, m1), cam, O.default_options(True), nx, ny, ns, 50)
+    got, _ = _render_gpu(rt, sp, m1, cam, nx, ny, ns, 50)
+    assert np.array_equal(_bits(got), _bits(ref))
+    m2 = mt.copy()
+    m2["type"][0] = rt.RT_FLOOR_CHECKER
+    m2["type"][485] = rt.RT_MODEL_SSS
+    m2["type"][small[::3]] = rt.RT_MODEL_TINTEDGLASS
+    ref, _ = O.render(O.sphere_scene(sp, m2), cam, O.default_options(True), nx, ny, ns, 50)
+    got, _ = _render_gpu(rt, sp, m2, cam, nx, ny, ns, 50)
+    rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
+    assert rel.mean() >= 0.995, rel.mean()

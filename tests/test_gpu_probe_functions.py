@@ -197,3 +197,26 @@ def test_material_scatter(rt, O, probe, lib):
         assert np.float32(sc.t) == tout[k]
         kinds.add((int(mats["type"][k]), int(flags[k])))
     assert (rt.RT_GLASS, 3) in kinds and (rt.RT_GLASS, 1) in kinds and (rt.RT_METAL, 1) in kinds and (rt.RT_DIFFUSE, 0) in kinds
+
+
+def test_dormant_presets_on_device(rt, O, probe):
+    """SURVEY.md §8 f-4 on the GPU, against the golden vectors minted from the reference's own preset functions.
+    Presets without libm calls (coat / diffuse / glossy / glass: kinds 3,4,6,7,8,9) are bit-exact.  The checker (sinf),
+    tinted glass (logf, expf) and subsurface (logf, expf) presets go through OCML on the device and glibc on the CPU:
+    same decisions and RNG consumption, values within 4e-6 relative."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "presets.npz"))
+    n = len(g["t"])
+    mats = np.zeros(n, rt.material_dtype)
+    mats["type"] = g["kind"]; mats["color"] = 0.5; mats["param"] = 1.5; mats["texId"] = -1
+    color = np.full((n, 3), 0.5, np.float32)
+    wi, thr, flags, tout, sa = probe.scatter(g["t"], g["normal"], g["inside"], g["wo"], mats, color, g["st_in"], hit_point=g["p"])
+    exact = np.isin(g["kind"], [3, 4, 6, 7, 8, 9])
+    assert np.array_equal(sa, g["st_out"]) and np.array_equal(flags, g["flags"])
+    assert np.array_equal(_bits(wi[exact]), _bits(g["wi"][exact]))
+    assert np.array_equal(_bits(thr[exact]), _bits(g["throughput"][exact]))
+    assert np.array_equal(_bits(tout[exact]), _bits(g["t_out"][exact]))
+    loose = ~exact
+    assert np.allclose(wi[loose], g["wi"][loose], rtol=4e-6, atol=1e-7)
+    assert np.allclose(thr[loose], g["throughput"][loose], rtol=4e-6, atol=1e-7)
+    assert np.allclose(tout[loose], g["t_out"][loose], rtol=4e-6, atol=1e-7)

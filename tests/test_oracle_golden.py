@@ -152,3 +152,27 @@ def test_benchmark_scene_is_the_fixture(rt):
     assert (mt["type"] == rt.RT_DIFFUSE).sum() + (mt["type"] == rt.RT_METAL).sum() + (mt["type"] == rt.RT_GLASS).sum() == 488
     assert tuple(sp[0]["center"]) == (0.0, -1000.0, -1.0) and sp[0]["radius"] == 1000.0
     assert mt[-1]["type"] == rt.RT_METAL and mt[-2]["type"] == rt.RT_DIFFUSE and mt[-3]["type"] == rt.RT_GLASS
+
+
+def test_dormant_presets(rt, O, lib):
+    """the reference's dormant look presets (scene_materials.h:22-93: coat, checker, tinted glass,
+    subsurface ...) restated in the oracle behind additive material types, against the reference's own preset functions
+    (tests/golden/presets.npz).  Bit-exact, libm calls (logf/expf/sinf) included: same glibc on both sides."""
+    g = np.load(os.path.join(G, "presets.npz"))
+    sc = O.orc_scatter()
+    seen = set()
+    for k in range(len(g["t"])):
+        m = rt.material(); m.type = int(g["kind"][k]); m.color.e[:] = (0.5, 0.5, 0.5); m.param = 1.5; m.texId = -1
+        st = C.c_uint32(int(g["st_in"][k]))
+        lib.orc_material_scatter_p(float(g["t"][k]), f3(g["p"][k]), f3(g["normal"][k]), int(g["inside"][k]), f3(g["wo"][k]),
+                                   C.byref(m), f3((0.5, 0.5, 0.5)), C.byref(st), C.byref(sc))
+        assert st.value == g["st_out"][k], k
+        assert (sc.specular | (sc.refracted << 1)) == g["flags"][k], k
+        assert np.array_equal(_bits(np.array(sc.wi[:])), _bits(g["wi"][k])), (k, int(g["kind"][k]))
+        assert np.array_equal(_bits(np.array(sc.throughput[:])), _bits(g["throughput"][k])), (k, int(g["kind"][k]))
+        assert np.float32(sc.t) == g["t_out"][k]
+        seen.add(int(g["kind"][k]))
+    assert seen == set(range(3, 12))
+    # the subsurface preset did scatter inside the medium somewhere (t shortened, direction not normalised)
+    sss = g["kind"] == rt.RT_MODEL_SSS
+    assert (g["t_out"][sss] < g["t"][sss]).any()
