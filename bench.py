@@ -106,10 +106,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # One rank per GPU.  (Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_BACKEND=gloo maps the ranks onto the
+    # GPUs that exist, round robin, and does the barrier / max over gloo; the driver's runs use nccl = RCCL.)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     import cuda_raytracing_optimized_amd as rt
     from cuda_raytracing_optimized_amd import multigpu
@@ -155,7 +162,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
-    stats = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(rays_local)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(rays_local)], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

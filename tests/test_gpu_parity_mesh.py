@@ -128,3 +128,18 @@ def test_mesh_stripe_partition_is_invisible(rt, stair):
         for k in range(r, (ny + 7) // 8, 3):
             merged[k * 8:(k + 1) * 8] = part[k * 8:(k + 1) * 8]
     assert np.array_equal(_bits(merged), _bits(whole))
+
+
+def test_mesh_fast_mode_within_tolerance(rt, O, stair):
+    """FAST fp build of the mesh kernel (FMA contraction, 2.5-ulp divide/sqrt): same RNG stream, chaotic fp divergence
+    (see the sphere-path test).  Stated tolerance at 96x120x4spp: >= 90 % of channels within 1e-3 absolute of the
+    oracle, image RMSE (main.cpp:117-125) <= 0.05 — the frame's own Monte-Carlo noise at 4 spp is several times that."""
+    hm, mats = stair
+    nx, ny, ns = 96, 120, 4
+    cam = rt.staircase_camera(nx, ny)
+    ref, _ = O.render(O.mesh_scene(hm, mats), cam, O.default_options(False), nx, ny, ns, 64)
+    got, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, fp=rt.RT_FP_FAST)
+    close = np.abs(got - ref) <= 1e-3
+    print("mesh fast: close", close.mean(), "rmse", rt.rmse(got, ref))
+    assert close.mean() >= 0.90
+    assert rt.rmse(got, ref) <= 0.05
