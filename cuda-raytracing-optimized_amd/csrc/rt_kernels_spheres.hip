@@ -508,14 +508,14 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done) {
+                                           uint32_t& groups_done, int sparse_max = kSparseRays) {
     // ---- hit(), kernels.cu:325-360: the ray is rebuilt from the path, which renormalises the direction
     const f3 dn = unit(L.dir);
     const float a = dot(dn, dn);
     Hit h = { FLT_MAX, -1, 0x7fffffff };
     const unsigned long long live = __ballot(has_ray);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
-        if (__popcll(live) <= kSparseRays && coop_below == -1) h = scan_sparse(P, S, L.org, dn, a, live, cull);
+        if (__popcll(live) <= sparse_max && coop_below == -1) h = scan_sparse(P, S, L.org, dn, a, live, cull);
         else h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done);
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
@@ -650,6 +650,46 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
     }
 }
 
+// ---- cost-ordered second phase ---------------------------------------------------------------------------------------
+// In the reference-stream mode the frame is rendered in two launches of the persistent kernel.  Phase 1 traces the first
+// `s_split` samples of every pixel and parks the pixel: RNG state, running colour sum, rays used.  This kernel then sorts the
+// pixels by that measured cost into the three work-order lists (class 0: >= 6 rays per sample so far — the candidates for
+// the very long chains; class 2: exactly one ray per sample — sky; class 1: the rest), and phase 2 resumes every pixel's
+// stream exactly where it stopped, longest jobs first.  No sample is traced twice and none is traced differently: the
+// stream, the order of the samples and the order of the additions into `col` are those of the single-launch kernel.
+__global__ void __launch_bounds__(kThreads) k_classify_by_cost(const RtSphereParams P) {
+    const int tiles_x = (P.nx + 7) >> 3;
+    const int tiles_y = (P.part.local_rows + 7) >> 3;
+    const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+    const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t tile = p >> 6, within = p & 63u;
+    const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
+    const int i = tx * 8 + (int)(within & 7u);
+    const int lr = ty * 8 + (int)(within >> 3);
+    const bool valid = p < total && i < P.nx && lr < P.part.local_rows;
+    int cls = 1;
+    if (valid) {
+        const uint32_t rays = P.px_rays[(size_t)lr * P.nx + i];
+        cls = rays >= 6u * (uint32_t)P.s_split ? 0 : (rays <= (uint32_t)P.s_split ? 2 : 1);
+    }
+    const unsigned long long m0 = __ballot(valid && cls == 0), m1 = __ballot(valid && cls == 1), m2 = __ballot(valid && cls == 2);
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (m0) b0 = atomicAdd(P.queue + 4, (uint32_t)__popcll(m0));
+        if (m1) b1 = atomicAdd(P.queue + 5, (uint32_t)__popcll(m1));
+        if (m2) b2 = atomicAdd(P.queue + 6, (uint32_t)__popcll(m2));
+    }
+    b0 = __builtin_amdgcn_readfirstlane(b0);
+    b1 = __builtin_amdgcn_readfirstlane(b1);
+    b2 = __builtin_amdgcn_readfirstlane(b2);
+    if (valid) {
+        const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
+        const uint32_t base = cls == 0 ? b0 : (cls == 1 ? b1 : b2);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        P.order[(uint32_t)cls * total + base + rank] = p;
+    }
+}
+
 // ---- variant 0 (default): persistent waves + pixel queue ----------------------------------------------------------
 // A pixel's samples are sequential (one RNG stream per pixel), so the pixel is the atom of work.  Pixels are
 // numbered tile-major (8x8 tiles, row-major tiles, row-major inside a tile) and handed out from ONE global
@@ -665,6 +705,8 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     float* unused;
     const SceneLds S = stage_scene(P, smem, &unused);
 
+    const int sparse_max = boost >> 8;
+    boost &= 0xFF;
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t padded = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
@@ -703,7 +745,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     // diagnostics (only when P.wave_dbg): 100 MHz time stamps and iteration counts of this wave
     const unsigned long long dbg_t0 = P.wave_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
-    uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0;
+    uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
     auto finish = [&](bool fin) {
@@ -713,7 +755,11 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             if (L.s < s_end) {
                 start_sample(P, L);
             } else {
-                if (K == 1u) {
+                if (P.phase == 1) {                                  // first samples done: park the pixel (RNG state, running sum, cost)
+                    const size_t px = (size_t)lr * P.nx + L.i;
+                    P.px_state[px] = make_float4(L.col.x, L.col.y, L.col.z, __uint_as_float(L.rng));
+                    P.px_rays[px] = pix_rays;
+                } else if (K == 1u) {
                     const f3 out = L.col / (float)P.ns;              // kernels.cu:568
                     float* dst = fbf + ((size_t)lr * P.nx + L.i) * 3;
                     dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
@@ -721,6 +767,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                     float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * K + (uint32_t)chunk) * 3;
                     dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
                 }
+                if (P.wave_dbg) dbg_maxpix = max(dbg_maxpix, pix_rays);
                 have_pixel = false;
             }
         }
@@ -782,10 +829,27 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 const int i = tx * 8 + (int)(within & 7u);
                 lr = ty * 8 + (int)(within >> 3);
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
-                    s_end = min(P.ns, (chunk + 1) * P.spw);
-                    start_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
+                    if (P.phase == 0) {
+                        s_end = min(P.ns, (chunk + 1) * P.spw);
+                        start_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
+                        pix_rays = 0;
+                    } else if (P.phase == 1) {
+                        s_end = P.s_split;
+                        start_pixel(P, L, i, global_row(P.part, lr), 0);
+                        pix_rays = 0;
+                    } else {                                         // resume: the pixel's stream continues where phase 1 left it
+                        s_end = P.ns;
+                        const size_t px = (size_t)lr * P.nx + i;
+                        const float4 st4 = P.px_state[px];
+                        L.i = i; L.j = global_row(P.part, lr);
+                        L.pixelId = (uint32_t)(L.j * P.nx + i);
+                        L.rng = __float_as_uint(st4.w);
+                        L.col = F3(st4.x, st4.y, st4.z);
+                        L.s = P.s_split;
+                        pix_rays = P.px_rays[px];
+                        start_sample(P, L);
+                    }
                     have_pixel = true;
-                    pix_rays = 0;
                 }
             }
         }
@@ -794,7 +858,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         if (P.wave_dbg) {
             if (exhausted && dbg_tex == 0ull) dbg_tex = __builtin_amdgcn_s_memrealtime();
             dbg_iters++;
-            if (__popcll(live_now) <= kSparseRays) dbg_coop_iters++;     // iterations in sparse form
+            if (__popcll(live_now) <= sparse_max) { dbg_coop_iters++; dbg_coop_rays += (uint32_t)__popcll(live_now); }   // sparse-form iterations / rays
         }
 
         // ---- one ray per live lane, then `boost` extra rays for the lanes on a long chain ---------------------------------
@@ -803,7 +867,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         // per full iteration; it gets `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
         // (One call site for both: the scan is large and must not be inlined twice.)
-        const int steps = (!LEGACY && boost > 0 && __popcll(live_now) > kSparseRays) ? 1 + boost : 1;
+        const int steps = (!LEGACY && boost > 0 && __popcll(live_now) > sparse_max) ? 1 + boost : 1;
         for (int x = 0; x < steps; x++) {
             bool sel = have_pixel;
             if (x > 0) {
@@ -812,10 +876,9 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 if (hm == 0ull) break;
                 const uint32_t hr = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                 sel = heavy && hr < (uint32_t)kSparseRays;           // at most kSparseRays of them per extra step
-                if (P.wave_dbg) dbg_coop_rays += (uint32_t)__popcll(__ballot(sel));
             }
             if (sel) { nrays++; pix_rays++; }
-            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done);
+            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max);
             finish(done && sel);
         }
     }
@@ -825,6 +888,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
         atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 16ull);     // lane-parallel phase-1 tests executed
     }
+    if (P.wave_dbg) atomicMax(P.wave_dbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
     if (P.wave_dbg && (threadIdx.x & 63) == 0) {
         unsigned long long* w = P.wave_dbg + ((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 8;
         w[0] = dbg_t0; w[1] = dbg_tex; w[2] = __builtin_amdgcn_s_memrealtime();
@@ -869,8 +933,9 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n, int threads) {
 //                      to the wave-cooperative scan when fewer than this many lanes of a wave have a ray
 //                      (1 = never cooperative, 65 = always cooperative);
 //          bit  26     disable sphere-group culling (every group is scanned: the plain brute-force scan);
-//          bits 24..25 work order of the persistent kernel: 0 = classified (hit-something pixels scattered, sky
-//                      pixels last; needs the classify pre-pass), 1 = tile-major, 2 = scattered only.
+//          bits 24..25 work order of the persistent kernel: 0 = two-phase, cost-ordered (reference stream; otherwise as 3),
+//                      1 = tile-major, 2 = scattered only, 3 = one launch ordered by the centre-ray pre-pass
+//                      (glass-crossing pixels first, sky last).
 hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
     const size_t lds = lds_bytes(p.n_padded, p.n);
     const int kind = variant & 0xFF;
@@ -884,9 +949,11 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         if (e != hipSuccess) return e;
     }
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
-    // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
+    // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 4, 7 = off)
     const int pb = (variant >> 27) & 7;
-    const int boost = pb == 7 ? 0 : (pb == 0 ? 2 : pb);
+    // bits 30..31: a wave switches to the sparse form at <= 4 / 8 / 12 / 16 live rays (0 = default)
+    const int sparse_max = 4 + 4 * ((variant >> 30) & 3);
+    const int boost = (pb == 7 ? 0 : (pb == 0 ? 4 : pb)) | (sparse_max << 8);
     int coop_below = (variant >> 16) & 0xFF;
     if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
     if (coop_below == 255) coop_below = -2;    // pair-compacted scan only (A/B)
@@ -911,21 +978,44 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // scattered order: stride ~ 0.618 * total, coprime with total
     uint32_t stride = 1;
     const int order_mode = (variant >> 24) & 3;
-    const int classified = (order_mode == 0 && p.order != nullptr) ? 1 : 0;
-    if (classified) {
-        hipLaunchKernelGGL(k_classify_spheres, dim3((unsigned)((total_px + kThreads - 1) / kThreads)), dim3(kThreads), lds, stream, p);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     if (order_mode != 1 && total_px > 64) {
         auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
         unsigned long long cand = (unsigned long long)((double)total_px * 0.6180339887) | 1ull;
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
-    if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, boost);
-    else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, p, coop_below, stride, classified, cull, boost);
-    e = hipGetLastError();
+    auto launch_queue = [&](const RtSphereParams& q, int classified) {
+        if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost);
+        else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost);
+        return hipGetLastError();
+    };
+    const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
+
+    // order_mode 0 (default), reference stream, enough samples: two phases — measure the cost of every pixel on its first
+    // samples, then resume all pixels longest-first (see k_classify_by_cost).  Otherwise: one launch, optionally ordered
+    // by the centre-ray pre-pass (k_classify_spheres: order_mode 3) or plainly scattered (2) / tile-major (1).
+    const int split = 2;
+    if (order_mode == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8) {
+        RtSphereParams q = p;
+        q.phase = 1; q.s_split = split;
+        e = launch_queue(q, 0);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(p.queue, 0, 64, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_classify_by_cost, dim3(cls_blocks), dim3(kThreads), 0, stream, q);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        q.phase = 2;
+        return launch_queue(q, 1);
+    }
+    int classified = 0;
+    if ((order_mode == 0 || order_mode == 3) && p.order != nullptr) {
+        hipLaunchKernelGGL(k_classify_spheres, dim3(cls_blocks), dim3(kThreads), lds, stream, p);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        classified = 1;
+    }
+    e = launch_queue(p, classified);
     if (e != hipSuccess) return e;
     if (p.chunks > 1) {
         const size_t npx = (size_t)p.part.local_rows * p.nx;

@@ -53,6 +53,11 @@ struct RtSphereParams {
     int32_t spw;                // samples per work item (= ns in the reference-stream mode: one item per pixel)
     int32_t chunks;             // work items per pixel = ceil(ns / spw)
     rt_vec3* partial;           // chunks > 1: local_rows * nx * chunks un-normalised partial sums
+    // two-phase rendering of the reference-stream mode (see rt_kernels_spheres.hip, "cost-ordered second phase"):
+    int32_t phase;              // 0 = single launch; 1 = first samples [0, s_split) -> per-pixel state; 2 = resume [s_split, ns)
+    int32_t s_split;            // samples rendered by phase 1
+    float4* px_state;           // local_rows * nx: (col.xyz, rng bits) after phase 1
+    uint32_t* px_rays;          // local_rows * nx: rays traced by phase 1
 };
 
 struct RtMeshParams {

@@ -69,6 +69,8 @@ struct DeviceState {
     uint32_t* d_order = nullptr;
     rt_vec3* d_partial = nullptr;
     size_t partial_bytes = 0;
+    float4* d_px_state = nullptr;       // two-phase rendering: per-pixel (col, rng) and rays after the first samples
+    uint32_t* d_px_rays = nullptr;
 };
 
 struct RenderContext {
@@ -128,7 +130,7 @@ void free_device(DeviceState& d) {
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
-    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial);
+    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays);
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
     if (d.ev_stop) HIP_CHECK(hipEventDestroy(d.ev_stop));
     if (d.stream) HIP_CHECK(hipStreamDestroy(d.stream));
@@ -197,6 +199,10 @@ void setup_devices() {
         if (d.fb_rows > 0) {        // work-order lists of the persistent kernels: 3 x (pixels padded to 8x8 tiles)
             const size_t padded = (size_t)((c.nx + 7) / 8) * ((d.fb_rows + 7) / 8) * 64;
             HIP_CHECK(hipMalloc((void**)&d.d_order, 3 * padded * sizeof(uint32_t)));
+            if (c.is_spheres) {
+                HIP_CHECK(hipMalloc((void**)&d.d_px_state, d.fb_rows * c.nx * sizeof(float4)));
+                HIP_CHECK(hipMalloc((void**)&d.d_px_rays, d.fb_rows * c.nx * sizeof(uint32_t)));
+            }
         }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
         HIP_CHECK(hipMemset(d.d_counters, 0, sizeof(RtCounters)));
@@ -459,6 +465,7 @@ void runRenderer(int ns, int tx, int ty) {
             // work items: one per pixel in the reference-stream mode (a pixel's samples are one sequential RNG stream);
             // with the per-sample counter stream the samples are independent and a pixel is split into chunks
             p.spw = ns; p.chunks = 1; p.partial = nullptr;
+            p.phase = 0; p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays;
             if (c.opt.rng == RT_RNG_COUNTER && (c.opt.variant & 0xFF) == 0) {
                 const int spw = c.opt.samples_per_item > 0 ? c.opt.samples_per_item : 4;
                 if (spw < ns) {

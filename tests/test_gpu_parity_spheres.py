@@ -33,7 +33,7 @@ def test_c1_three_spheres_bit_exact(rt, O, nx, ny, ns):
 
 # kernel variants (rt_kernels_spheres.hip): 0 = persistent waves + pixel queue (default), 1 = one tile per wave;
 # bits 8..15 workgroups per CU, bits 16..23 cooperative-scan threshold, bits 24..25 work order, bit 26 = culling off
-@pytest.mark.parametrize("variant", [0, 1, (1 << 8), (8 << 8), (1 << 24), (2 << 24), (24 << 16), (65 << 16), (1 << 16) + 1, (1 << 26), (1 << 26) + 1, (1 << 26) + (65 << 16)])
+@pytest.mark.parametrize("variant", [0, 1, (1 << 8), (8 << 8), (1 << 24), (2 << 24), (3 << 24), (24 << 16), (65 << 16), (1 << 16) + 1, (1 << 26), (1 << 26) + 1, (1 << 26) + (65 << 16)])
 @pytest.mark.parametrize("nx,ny,ns", [(300, 200, 2), (120, 80, 8), (61, 37, 5)])
 def test_random_spheres_bit_exact(rt, O, nx, ny, ns, variant):
     sp, mt, cam = rt.scene_random_spheres(nx, ny)

@@ -11,14 +11,14 @@ print("waves", len(a), "kernel span ms %.2f" % end.max())
 print("start   ms: min %.2f max %.2f" % (start.min(), start.max()))
 print("exhaust ms: min %.2f median %.2f max %.2f" % (np.nanmin(tex), np.nanmedian(tex), np.nanmax(tex)))
 print("end     ms: p10 %.2f median %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(end, [10, 50, 90, 99, 100])))
-print("iterations per wave: mean %.0f max %d | sparse-form iterations: mean %.0f max %d | boost rays mean %.0f max %d" %
+print("iterations per wave: mean %.0f max %d | sparse-form iterations: mean %.0f max %d | sparse-form rays mean %.0f max %d" %
       (a[:, 3].mean(), a[:, 3].max(), a[:, 4].mean(), a[:, 4].max(), a[:, 5].mean(), a[:, 5].max()))
 hist, edges = np.histogram(end, bins=20)
 for h, e in zip(hist, edges):
     print("  end in [%6.2f, ..) ms: %5d waves" % (e, h))
 late = np.argsort(end)[-5:]
 for w in late:
-    print("  late wave: end %.2f exhausted %.2f iters %d sparse_iters %d boost_rays %d" % (end[w], tex[w], a[w, 3], a[w, 4], a[w, 5]))
+    print("  late wave: end %.2f exhausted %.2f iters %d sparse_iters %d sparse_rays %d" % (end[w], tex[w], a[w, 3], a[w, 4], a[w, 5]))
 
 early = end < 1.0
 print("early waves:", early.sum(), "their iters: mean %.1f max %d" % (a[early, 3].mean() if early.any() else 0, a[early, 3].max() if early.any() else 0))
