@@ -508,14 +508,18 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done, int sparse_max = kSparseRays) {
+                                           uint32_t& groups_done, int sparse_max = kSparseRays, unsigned long long* cyc = nullptr) {
     // ---- hit(), kernels.cu:325-360: the ray is rebuilt from the path, which renormalises the direction
     const f3 dn = unit(L.dir);
     const float a = dot(dn, dn);
     Hit h = { FLT_MAX, -1, 0x7fffffff };
     const unsigned long long live = __ballot(has_ray);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
-        if (__popcll(live) <= sparse_max && coop_below == -1) h = scan_sparse(P, S, L.org, dn, a, live, cull);
+        if (__popcll(live) <= sparse_max && coop_below == -1) {
+            const unsigned long long c0 = cyc ? __builtin_amdgcn_s_memtime() : 0ull;
+            h = scan_sparse(P, S, L.org, dn, a, live, cull);
+            if (cyc) { cyc[0] += __builtin_amdgcn_s_memtime() - c0; cyc[1] += 1; }
+        }
         else h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done);
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
@@ -530,7 +534,9 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
         }
     }
     bool done = false;
+    const unsigned long long c1 = cyc ? __builtin_amdgcn_s_memtime() : 0ull;
     if (has_ray) done = shade(P, S, L, dn, h);
+    if (cyc) cyc[2] += __builtin_amdgcn_s_memtime() - c1;
     return done;
 }
 
@@ -652,41 +658,81 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
 
 // ---- cost-ordered second phase ---------------------------------------------------------------------------------------
 // In the reference-stream mode the frame is rendered in two launches of the persistent kernel.  Phase 1 traces the first
-// `s_split` samples of every pixel and parks the pixel: RNG state, running colour sum, rays used.  This kernel then sorts the
-// pixels by that measured cost into the three work-order lists (class 0: >= 6 rays per sample so far — the candidates for
-// the very long chains; class 2: exactly one ray per sample — sky; class 1: the rest), and phase 2 resumes every pixel's
-// stream exactly where it stopped, longest jobs first.  No sample is traced twice and none is traced differently: the
-// stream, the order of the samples and the order of the additions into `col` are those of the single-launch kernel.
-__global__ void __launch_bounds__(kThreads) k_classify_by_cost(const RtSphereParams P) {
+// `s_split` samples of every pixel and parks the pixel: RNG state, running colour sum, rays used.  k_order_by_cost then
+// sorts the pixels by that measured cost into kCostClasses lists, and phase 2 resumes every pixel's stream exactly where
+// it stopped, longest jobs first.  No sample is traced twice and none is traced differently: the stream, the order of the
+// samples and the order of the additions into `col` are those of the single-launch kernel.
+//
+// Cost estimate of a pixel = rays per sample so far, averaged over the pixel and its (up to 8) neighbours: the
+// neighbours see almost the same scene, so this is an 18-sample estimate instead of a 2-sample one.  A lane that is
+// not on a boosted chain advances one ray per wave iteration, so a pixel handed out at time T ends near
+// T + rays x iteration time: the classes are narrow (x1.25 steps) so that the pixels handed out last are the cheapest.
+// class 0: >= 6 rays per sample (candidates for the very long chains); class kCostClasses-1: one ray per sample in the
+// whole window (sky).  Two passes (PASS 0 counts, PASS 1 fills) make the lists compact: P.order holds each pixel once.
+// P.queue[4 + c] = length of list c;  P.queue[4 + kCostClasses + c] = fill cursor of list c.
+constexpr int kCostClasses = 12;
+
+__device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr) {
+    uint32_t sum = 0, cnt = 0;
+    for (int dy = -1; dy <= 1; dy++) {
+        const int y = lr + dy;
+        if (y < 0 || y >= P.part.local_rows) continue;
+        for (int dx = -1; dx <= 1; dx++) {
+            const int x = i + dx;
+            if (x < 0 || x >= P.nx) continue;
+            sum += P.px_rays[(size_t)y * P.nx + x];
+            cnt++;
+        }
+    }
+    // e = 16 x (rays per sample); >= 16 always (every sample starts with one ray)
+    const uint32_t e = (sum * 16u) / (cnt * (uint32_t)P.s_split);
+    const uint32_t lim[kCostClasses - 1] = { 96u, 72u, 56u, 44u, 36u, 30u, 26u, 22u, 19u, 18u, 17u };
+    int cls = kCostClasses - 1;
+#pragma unroll
+    for (int c = kCostClasses - 2; c >= 0; c--) if (e >= lim[c]) cls = c;
+    return cls;
+}
+
+// Each workgroup owns a contiguous range of pixel slots, counts its classes in LDS and touches the global counters once
+// per class (a global atomic per wave and class would serialise on 12 addresses: 1.7 ms instead of 40 us).
+constexpr int kOrderBlocks = 1024;
+
+template <int PASS>
+__global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams P) {
+    __shared__ uint32_t s_cnt[kCostClasses], s_base[kCostClasses];
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
-    const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
-    const uint32_t tile = p >> 6, within = p & 63u;
-    const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
-    const int i = tx * 8 + (int)(within & 7u);
-    const int lr = ty * 8 + (int)(within >> 3);
-    const bool valid = p < total && i < P.nx && lr < P.part.local_rows;
-    int cls = 1;
-    if (valid) {
-        const uint32_t rays = P.px_rays[(size_t)lr * P.nx + i];
-        cls = rays >= 6u * (uint32_t)P.s_split ? 0 : (rays <= (uint32_t)P.s_split ? 2 : 1);
+    const uint32_t per = ((total + gridDim.x - 1u) / gridDim.x + (uint32_t)kThreads - 1u) / (uint32_t)kThreads * (uint32_t)kThreads;
+    const uint32_t first = blockIdx.x * per, last = min(first + per, total);
+    auto class_of = [&](uint32_t p) {
+        const uint32_t tile = p >> 6, within = p & 63u;
+        const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
+        const int i = tx * 8 + (int)(within & 7u);
+        const int lr = ty * 8 + (int)(within >> 3);
+        return (p < last && i < P.nx && lr < P.part.local_rows) ? cost_class(P, i, lr) : -1;
+    };
+    if (threadIdx.x < kCostClasses) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t p = first + threadIdx.x; p < last; p += kThreads) {
+        const int cls = class_of(p);
+        if (cls >= 0) atomicAdd(&s_cnt[cls], 1u);
     }
-    const unsigned long long m0 = __ballot(valid && cls == 0), m1 = __ballot(valid && cls == 1), m2 = __ballot(valid && cls == 2);
-    uint32_t b0 = 0, b1 = 0, b2 = 0;
-    if ((threadIdx.x & 63) == 0) {
-        if (m0) b0 = atomicAdd(P.queue + 4, (uint32_t)__popcll(m0));
-        if (m1) b1 = atomicAdd(P.queue + 5, (uint32_t)__popcll(m1));
-        if (m2) b2 = atomicAdd(P.queue + 6, (uint32_t)__popcll(m2));
+    __syncthreads();
+    if (PASS == 0) {
+        if (threadIdx.x < kCostClasses && s_cnt[threadIdx.x]) atomicAdd(P.queue + 4 + threadIdx.x, s_cnt[threadIdx.x]);
+        return;
     }
-    b0 = __builtin_amdgcn_readfirstlane(b0);
-    b1 = __builtin_amdgcn_readfirstlane(b1);
-    b2 = __builtin_amdgcn_readfirstlane(b2);
-    if (valid) {
-        const unsigned long long m = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
-        const uint32_t base = cls == 0 ? b0 : (cls == 1 ? b1 : b2);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        P.order[(uint32_t)cls * total + base + rank] = p;
+    if (threadIdx.x < kCostClasses) {
+        uint32_t start = 0;                                          // first position of this list in P.order
+        for (int c = 0; c < (int)threadIdx.x; c++) start += P.queue[4 + c];
+        s_base[threadIdx.x] = start + (s_cnt[threadIdx.x] ? atomicAdd(P.queue + 4 + kCostClasses + threadIdx.x, s_cnt[threadIdx.x]) : 0u);
+        s_cnt[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t p = first + threadIdx.x; p < last; p += kThreads) {
+        const int cls = class_of(p);
+        if (cls >= 0) P.order[s_base[cls] + atomicAdd(&s_cnt[cls], 1u)] = p;
     }
 }
 
@@ -710,13 +756,12 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t padded = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
-    // classified order: queue positions [0, n0) walk class 0 (glass), [n0, n0+n1) class 1, both in a scattered order,
-    // then class 2 (sky) in list order
-    const uint32_t n0 = classified ? P.queue[4] : 0u, n1 = classified ? P.queue[5] : 0u, n2 = classified ? P.queue[6] : 0u;
-    const uint32_t total_px = classified ? n0 + n1 + n2 : padded;
-    const uint32_t K = (uint32_t)P.chunks;                           // work items per pixel (1 unless RT_RNG_COUNTER)
-    const uint32_t total = total_px * K;
-    auto coprime_stride = [](uint32_t n) {                           // ~0.618 n, coprime with n (wave-uniform)
+    // classified order (classified = 1: the three lists of k_classify_spheres, each `padded` apart in P.order;
+    // classified = 2: the kCostClasses compact lists of k_order_by_cost).  Queue positions walk list 0 (the long chains)
+    // first, then the other lists in order; inside a list the order is scattered, except the last (sky) list.
+    __shared__ uint32_t s_cls_base[kCostClasses], s_cls_pos[kCostClasses + 1], s_cls_stride[kCostClasses];
+    const int n_cls = classified == 2 ? kCostClasses : (classified == 1 ? 3 : 0);
+    auto coprime_stride = [](uint32_t n) {                           // ~0.618 n, coprime with n
         if (n <= 64u) return 1u;
         uint32_t c = ((uint32_t)((unsigned long long)n * 2654435769ull >> 32)) | 1u;
         for (;;) {
@@ -727,9 +772,25 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         }
         return c % n;
     };
-    const uint32_t stride0 = classified ? coprime_stride(n0) : 1u, stride1 = classified ? coprime_stride(n1) : 1u;
+    if (threadIdx.x == 0) {
+        uint32_t pos = 0;
+        for (int c = 0; c < n_cls; c++) {
+            const uint32_t n = P.queue[4 + c];
+            s_cls_base[c] = classified == 2 ? pos : (uint32_t)c * padded;
+            s_cls_pos[c] = pos;
+            s_cls_stride[c] = (c == n_cls - 1) ? 1u : coprime_stride(n);
+            pos += n;
+        }
+        for (int c = n_cls; c <= kCostClasses; c++) s_cls_pos[c] = pos;
+    }
+    __syncthreads();
+    const uint32_t n0 = n_cls ? s_cls_pos[1] : 0u;
+    const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] : padded;
+    const uint32_t n_rest = total_px - n0;
+    const uint32_t K = (uint32_t)P.chunks;                           // work items per pixel (1 unless RT_RNG_COUNTER)
+    const uint32_t total = total_px * K;
     const uint32_t spread = gridDim.x * (uint32_t)kThreads;          // lanes in flight
-    const bool spread_ok = n0 > 0u && n0 <= spread && (spread - n0) <= n1;
+    const bool spread_ok = n0 > 0u && n0 <= spread && (spread - n0) <= n_rest;
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -746,6 +807,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     const unsigned long long dbg_t0 = P.wave_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
+    unsigned long long dbg_cyc[4] = { 0, 0, 0, 0 };   // boost steps: scan cycles, count, shade cycles, whole-step cycles
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
     auto finish = [&](bool fin) {
@@ -805,10 +867,10 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 chunk = (int)(item - pos * K);
                 uint32_t p;
                 if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
-                else if (pos < n0 + n1) {
-                    // classes 0 and 1: the n0 glass pixels are spread evenly over the first `spread` queue positions
-                    // (= the lanes in flight at t = 0), so every wave starts with a few of them instead of a few waves
-                    // with nothing else; position p is a class-0 position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
+                else {
+                    // the n0 pixels of list 0 are spread evenly over the first `spread` queue positions (= the lanes in
+                    // flight at t = 0), so every wave starts with a few of them instead of a few waves with nothing
+                    // else; position p is a list-0 position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
                     uint32_t i0, i1;
                     bool is0;
                     if (spread_ok && pos < spread) {
@@ -820,10 +882,17 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                     } else {
                         is0 = pos < n0; i0 = pos; i1 = pos - n0;
                     }
-                    p = is0 ? P.order[(uint32_t)(((unsigned long long)i0 * stride0) % n0)]
-                            : P.order[padded + (uint32_t)(((unsigned long long)i1 * stride1) % n1)];
+                    int c = 0;
+                    uint32_t j = i0;
+                    if (!is0) {
+                        const uint32_t q = n0 + i1;                  // position in the concatenation of all lists
+                        c = 1;
+                        for (int k = 2; k < kCostClasses; k++) if (q >= s_cls_pos[k]) c = k;
+                        j = q - s_cls_pos[c];
+                    }
+                    const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
+                    p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
                 }
-                else p = P.order[2u * padded + (pos - n0 - n1)];
                 const uint32_t tile = p >> 6, within = p & 63u;
                 const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
                 const int i = tx * 8 + (int)(within & 7u);
@@ -878,7 +947,12 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 sel = heavy && hr < (uint32_t)kSparseRays;           // at most kSparseRays of them per extra step
             }
             if (sel) { nrays++; pix_rays++; }
-            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max);
+            if (!LEGACY) {
+                if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            }
+            const unsigned long long cs = (P.wave_dbg && x > 0) ? __builtin_amdgcn_s_memtime() : 0ull;
+            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max, (P.wave_dbg && x > 0) ? dbg_cyc : nullptr);
+            if (P.wave_dbg && x > 0) dbg_cyc[3] += __builtin_amdgcn_s_memtime() - cs;
             finish(done && sel);
         }
     }
@@ -964,7 +1038,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         return hipGetLastError();
     }
     if (!p.queue) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(p.queue, 0, 64, stream);
+    hipError_t e = hipMemsetAsync(p.queue, 0, 256, stream);
     if (e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -994,19 +1068,20 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // order_mode 0 (default), reference stream, enough samples: two phases — measure the cost of every pixel on its first
     // samples, then resume all pixels longest-first (see k_classify_by_cost).  Otherwise: one launch, optionally ordered
     // by the centre-ray pre-pass (k_classify_spheres: order_mode 3) or plainly scattered (2) / tile-major (1).
-    const int split = 2;
+    const int split = 2;                                             // measured: 2 -> 24.5 ms, 4 -> 24.8, 6 -> 25.4
     if (order_mode == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8) {
         RtSphereParams q = p;
         q.phase = 1; q.s_split = split;
         e = launch_queue(q, 0);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(p.queue, 0, 64, stream);
+        e = hipMemsetAsync(p.queue, 0, 256, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_classify_by_cost, dim3(cls_blocks), dim3(kThreads), 0, stream, q);
+        hipLaunchKernelGGL(k_order_by_cost<0>, dim3(kOrderBlocks), dim3(kThreads), 0, stream, q);
+        hipLaunchKernelGGL(k_order_by_cost<1>, dim3(kOrderBlocks), dim3(kThreads), 0, stream, q);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         q.phase = 2;
-        return launch_queue(q, 1);
+        return launch_queue(q, 2);
     }
     int classified = 0;
     if ((order_mode == 0 || order_mode == 3) && p.order != nullptr) {

@@ -206,8 +206,8 @@ void setup_devices() {
         }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
         HIP_CHECK(hipMemset(d.d_counters, 0, sizeof(RtCounters)));
-        HIP_CHECK(hipMalloc((void**)&d.d_queue, 64));
-        HIP_CHECK(hipMemset(d.d_queue, 0, 64));
+        HIP_CHECK(hipMalloc((void**)&d.d_queue, 256));
+        HIP_CHECK(hipMemset(d.d_queue, 0, 256));
         c.devs.push_back(d);
     }
     HIP_CHECK(hipSetDevice(current));
