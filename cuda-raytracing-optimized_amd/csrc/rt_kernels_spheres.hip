@@ -670,7 +670,9 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
 // class 0: >= 6 rays per sample (candidates for the very long chains); class kCostClasses-1: one ray per sample in the
 // whole window (sky).  Two passes (PASS 0 counts, PASS 1 fills) make the lists compact: P.order holds each pixel once.
 // P.queue[4 + c] = length of list c;  P.queue[4 + kCostClasses + c] = fill cursor of list c.
-constexpr int kCostClasses = 12;
+constexpr int kCostClasses = 17;
+constexpr int kChainClasses = 3;      // lists 0..2: >= 12 rays per sample, the chains -> chain waves (see k_render_spheres_queue)
+constexpr int kHeavyClasses = 3;      // lists 3..5: 6..12 rays per sample -> spread over the first fill of the normal waves
 
 __device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr) {
     uint32_t sum = 0, cnt = 0;
@@ -686,7 +688,7 @@ __device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr
     }
     // e = 16 x (rays per sample); >= 16 always (every sample starts with one ray)
     const uint32_t e = (sum * 16u) / (cnt * (uint32_t)P.s_split);
-    const uint32_t lim[kCostClasses - 1] = { 96u, 72u, 56u, 44u, 36u, 30u, 26u, 22u, 19u, 18u, 17u };
+    const uint32_t lim[kCostClasses - 1] = { 320u, 240u, 192u, 160u, 128u, 96u, 72u, 56u, 44u, 36u, 30u, 26u, 22u, 19u, 18u, 17u };
     int cls = kCostClasses - 1;
 #pragma unroll
     for (int c = kCostClasses - 2; c >= 0; c--) if (e >= lim[c]) cls = c;
@@ -746,7 +748,7 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 
 template <bool LEGACY>
 __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
-                                                                   int cull, int boost) {
+                                                                   int cull, int boost, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
     const SceneLds S = stage_scene(P, smem, &unused);
@@ -784,13 +786,30 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         for (int c = n_cls; c <= kCostClasses; c++) s_cls_pos[c] = pos;
     }
     __syncthreads();
-    const uint32_t n0 = n_cls ? s_cls_pos[1] : 0u;
-    const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] : padded;
+    // classified = 2 (tiered): lists [0, n_chain) are the chain lists, the lists up to kChainClasses + kHeavyClasses the
+    // heavy lists, the remaining ones the rest.  classified = 1: no chain lists; list 0 is the heavy list.
+    const bool tiered = classified == 2;
+    const int n_chain = tiered ? ((chain_cfg >> 24) & 0xF) : 0;
+    const uint32_t nA = tiered ? s_cls_pos[n_chain] : 0u;
+    const uint32_t n0 = tiered ? s_cls_pos[kChainClasses + kHeavyClasses] - nA : (n_cls ? s_cls_pos[1] : 0u);   // heavy pixels
+    const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] - nA : padded;       // pixels in the general queue
     const uint32_t n_rest = total_px - n0;
     const uint32_t K = (uint32_t)P.chunks;                           // work items per pixel (1 unless RT_RNG_COUNTER)
     const uint32_t total = total_px * K;
     const uint32_t spread = gridDim.x * (uint32_t)kThreads;          // lanes in flight
     const bool spread_ok = n0 > 0u && n0 <= spread && (spread - n0) <= n_rest;
+    // Chain waves.  A lane that is not boosted advances ONE ray per wave iteration, and an iteration takes 3-4 us for <= 4
+    // live lanes (sparse form) but 15-25 us for 64: a pixel handed out at time T ends near T + rays x iteration time, and
+    // the longest pixels (3700 rays: 50 bounces inside glass, sample after sample) would end the frame at 60 ms.
+    // So one wave in twelve (role 0: wave 0 of every third workgroup) serves the chain lists from their own counter
+    // (P.queue[1]), longest first, and holds at most kSparseRays pixels: it always runs the sparse form, at raised
+    // priority, and the longest chain is over after 15 ms.  When the chain lists are empty the wave becomes a normal wave
+    // (role 2: general queue, all 64 lanes), but keeps the cap for as long as it still holds a chain pixel.
+    // (Tried and dropped: half-occupied "medium" waves for the heavy lists - what they gain in the tail they lose in throughput.)
+    const uint32_t heavy_thr = (uint32_t)((chain_cfg >> 16) & 0xFF);
+    int role = 2;
+    if (nA > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
+    int tier = 2;                       // tier of the lane's pixel (= role of the wave when it was fetched)
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -807,6 +826,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     const unsigned long long dbg_t0 = P.wave_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
+    float dbg_grab = 0.0f, dbg_p1 = 0.0f;                           // this lane's pixel: time it was grabbed, rays of phase 1
     unsigned long long dbg_cyc[4] = { 0, 0, 0, 0 };   // boost steps: scan cycles, count, shade cycles, whole-step cycles
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
@@ -829,7 +849,11 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                     float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * K + (uint32_t)chunk) * 3;
                     dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
                 }
-                if (P.wave_dbg) dbg_maxpix = max(dbg_maxpix, pix_rays);
+                if (P.wave_dbg) {
+                    dbg_maxpix = max(dbg_maxpix, pix_rays);
+                    if (P.phase == 2)                                // per-pixel time line: (grabbed, finished) in ms, rays in total, rays in phase 1
+                        P.px_state[(size_t)lr * P.nx + L.i] = make_float4(dbg_grab, (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f, (float)pix_rays, dbg_p1);
+                }
                 have_pixel = false;
             }
         }
@@ -838,7 +862,15 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     while (true) {
         // ---- refill idle lanes --------------------------------------------------------------------------------
         while (!exhausted) {
-            const unsigned long long need = __ballot(!have_pixel);
+            // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
+            const unsigned long long live_m = __ballot(have_pixel);
+            const bool hold0 = __ballot(have_pixel && tier == 0) != 0ull;
+            const int cap = (role == 0 || hold0) ? kSparseRays : 64;
+            const int allowed = cap - (int)__popcll(live_m);
+            if (allowed <= 0) break;
+            const unsigned long long idle_m = ~live_m;
+            const uint32_t idle_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+            const unsigned long long need = __ballot(!have_pixel && idle_rank < (uint32_t)allowed);
             if (need == 0ull) break;
             // Whole pixels (K == 1): reserve exactly as many as there are idle lanes, so nothing is hoarded in a wave while
             // other waves idle.  Sample chunks (K > 1, counter RNG): items are small and plentiful, one atomic per idle
@@ -846,18 +878,23 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             const uint32_t cnt = (uint32_t)__popcll(need);
             if (pool_next >= pool_end) {
                 const uint32_t grab = (K > 1u) ? max(cnt, 128u) : cnt;
+                const uint32_t limit = role == 0 ? nA : total;
                 uint32_t b = 0;
-                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue, grab);
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : 0), grab);
                 b = __builtin_amdgcn_readfirstlane(b);
-                if (b >= total) { exhausted = true; break; }
+                if (b >= limit) {
+                    if (role < 2) { role = 2; continue; }            // this wave's lists are empty: a normal wave from now on
+                    exhausted = true;
+                    break;
+                }
                 pool_next = b;
-                pool_end = min(b + grab, total);
+                pool_end = min(b + grab, limit);
             }
             const uint32_t base = pool_next;
             const uint32_t take = min(cnt, pool_end - pool_next);
             pool_next += take;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (pool_next >= total) exhausted = true;                // this grab took the last items
+            if (role == 2 && pool_next >= total) exhausted = true;   // this grab took the last items
             if (!have_pixel && rank < take) {
                 // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
                 // neighbouring pixels over different waves, so the few very long pixels (paths trapped inside
@@ -868,28 +905,28 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                 uint32_t p;
                 if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
                 else {
-                    // the n0 pixels of list 0 are spread evenly over the first `spread` queue positions (= the lanes in
+                    // the n0 pixels of the heavy lists are spread evenly over the first `spread` queue positions (= the lanes in
                     // flight at t = 0), so every wave starts with a few of them instead of a few waves with nothing
-                    // else; position p is a list-0 position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
-                    uint32_t i0, i1;
-                    bool is0;
-                    if (spread_ok && pos < spread) {
-                        const uint32_t before = (uint32_t)(((unsigned long long)pos * n0) / spread);
-                        const uint32_t after = (uint32_t)(((unsigned long long)(pos + 1u) * n0) / spread);
-                        is0 = after > before; i0 = before; i1 = pos - before;
-                    } else if (spread_ok) {
-                        is0 = false; i0 = 0; i1 = pos - n0;
-                    } else {
-                        is0 = pos < n0; i0 = pos; i1 = pos - n0;
+                    // else; position p is a heavy-list position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
+                    uint32_t q;                                      // position in the concatenation of all lists
+                    if (role == 0) q = pos;
+                    else {
+                        uint32_t i0, i1;
+                        bool is0;
+                        if (spread_ok && pos < spread) {
+                            const uint32_t before = (uint32_t)(((unsigned long long)pos * n0) / spread);
+                            const uint32_t after = (uint32_t)(((unsigned long long)(pos + 1u) * n0) / spread);
+                            is0 = after > before; i0 = before; i1 = pos - before;
+                        } else if (spread_ok) {
+                            is0 = false; i0 = 0; i1 = pos - n0;
+                        } else {
+                            is0 = pos < n0; i0 = pos; i1 = pos - n0;
+                        }
+                        q = nA + (is0 ? i0 : n0 + i1);
                     }
                     int c = 0;
-                    uint32_t j = i0;
-                    if (!is0) {
-                        const uint32_t q = n0 + i1;                  // position in the concatenation of all lists
-                        c = 1;
-                        for (int k = 2; k < kCostClasses; k++) if (q >= s_cls_pos[k]) c = k;
-                        j = q - s_cls_pos[c];
-                    }
+                    for (int k = 1; k < kCostClasses; k++) if (q >= s_cls_pos[k]) c = k;
+                    const uint32_t j = q - s_cls_pos[c];
                     const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
                     p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
                 }
@@ -916,9 +953,11 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                         L.col = F3(st4.x, st4.y, st4.z);
                         L.s = P.s_split;
                         pix_rays = P.px_rays[px];
+                        if (P.wave_dbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
                         start_sample(P, L);
                     }
                     have_pixel = true;
+                    tier = role;
                 }
             }
         }
@@ -940,11 +979,17 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         for (int x = 0; x < steps; x++) {
             bool sel = have_pixel;
             if (x > 0) {
-                const bool heavy = have_pixel && pix_rays > 10u * (uint32_t)(L.s - chunk * P.spw + 2);
+                const bool heavy = have_pixel && pix_rays > heavy_thr * (uint32_t)(L.s - chunk * P.spw + 2);
                 const unsigned long long hm = __ballot(heavy);
                 if (hm == 0ull) break;
-                const uint32_t hr = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                sel = heavy && hr < (uint32_t)kSparseRays;           // at most kSparseRays of them per extra step
+                // at most kSparseRays of them per extra step, taking turns: step x serves the heavy lanes of rank
+                // [4 (x-1), 4 x) mod their number (all of them when there are <= 4)
+                const int h = (int)__popcll(hm);
+                const int hr = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                const int start = h > kSparseRays ? ((x - 1) * kSparseRays) % h : 0;
+                int d = hr - start;
+                if (d < 0) d += h;
+                sel = heavy && d < kSparseRays;
             }
             if (sel) { nrays++; pix_rays++; }
             if (!LEGACY) {
@@ -1058,9 +1103,12 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
+    // chain waves: wave 0 of every 3rd workgroup; lanes above 10 rays per sample are boosted; chain lists = the first kChainClasses
+    // (measured on C2: every third / 10 / 3 is the optimum of a flat basin)
+    const int chain_cfg = 3 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
     auto launch_queue = [&](const RtSphereParams& q, int classified) {
-        if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost);
-        else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost);
+        if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
+        else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
         return hipGetLastError();
     };
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);

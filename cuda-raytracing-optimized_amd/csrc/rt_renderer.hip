@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/rt_api.h"
@@ -539,6 +540,12 @@ void runRenderer(int ns, int tx, int ty) {
             std::vector<unsigned long long> h((size_t)65536 * 8);
             HIP_CHECK(hipMemcpy(h.data(), d.d_wave_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE* f = fopen(getenv("RT_WAVE_DEBUG"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+            if (d.d_px_state) {                                      // per-pixel time line of the second phase (see finish())
+                std::vector<float> px((size_t)d.fb_rows * c.nx * 4);
+                HIP_CHECK(hipMemcpy(px.data(), d.d_px_state, px.size() * sizeof(float), hipMemcpyDeviceToHost));
+                const std::string path = std::string(getenv("RT_WAVE_DEBUG")) + ".px";
+                if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(px.data(), sizeof(float), px.size(), f); fclose(f); }
+            }
         }
         if (c.opt.counters) {
             RtCounters h;
