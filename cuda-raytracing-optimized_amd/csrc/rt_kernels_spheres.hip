@@ -508,18 +508,14 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done, int sparse_max = kSparseRays, unsigned long long* cyc = nullptr) {
+                                           uint32_t& groups_done, int sparse_max = kSparseRays) {
     // ---- hit(), kernels.cu:325-360: the ray is rebuilt from the path, which renormalises the direction
     const f3 dn = unit(L.dir);
     const float a = dot(dn, dn);
     Hit h = { FLT_MAX, -1, 0x7fffffff };
     const unsigned long long live = __ballot(has_ray);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
-        if (__popcll(live) <= sparse_max && coop_below == -1) {
-            const unsigned long long c0 = cyc ? __builtin_amdgcn_s_memtime() : 0ull;
-            h = scan_sparse(P, S, L.org, dn, a, live, cull);
-            if (cyc) { cyc[0] += __builtin_amdgcn_s_memtime() - c0; cyc[1] += 1; }
-        }
+        if (__popcll(live) <= sparse_max && coop_below == -1) h = scan_sparse(P, S, L.org, dn, a, live, cull);
         else h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done);
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
@@ -534,9 +530,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
         }
     }
     bool done = false;
-    const unsigned long long c1 = cyc ? __builtin_amdgcn_s_memtime() : 0ull;
     if (has_ray) done = shade(P, S, L, dn, h);
-    if (cyc) cyc[2] += __builtin_amdgcn_s_memtime() - c1;
     return done;
 }
 
@@ -827,7 +821,6 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
     float dbg_grab = 0.0f, dbg_p1 = 0.0f;                           // this lane's pixel: time it was grabbed, rays of phase 1
-    unsigned long long dbg_cyc[4] = { 0, 0, 0, 0 };   // boost steps: scan cycles, count, shade cycles, whole-step cycles
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
     auto finish = [&](bool fin) {
@@ -843,8 +836,9 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                     P.px_rays[px] = pix_rays;
                 } else if (K == 1u) {
                     const f3 out = L.col / (float)P.ns;              // kernels.cu:568
-                    float* dst = fbf + ((size_t)lr * P.nx + L.i) * 3;
-                    dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+                    // one 12-byte store (global_store_dwordx3): a lane finishes its pixel on its own, so three dword
+                    // stores would be three partial-sector writes to HBM
+                    *reinterpret_cast<float3*>(fbf + ((size_t)lr * P.nx + L.i) * 3) = make_float3(out.x, out.y, out.z);
                 } else {                                             // partial sum of this chunk; k_sum_chunks adds them in order
                     float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * K + (uint32_t)chunk) * 3;
                     dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
@@ -995,9 +989,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             if (!LEGACY) {
                 if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             }
-            const unsigned long long cs = (P.wave_dbg && x > 0) ? __builtin_amdgcn_s_memtime() : 0ull;
-            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max, (P.wave_dbg && x > 0) ? dbg_cyc : nullptr);
-            if (P.wave_dbg && x > 0) dbg_cyc[3] += __builtin_amdgcn_s_memtime() - cs;
+            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max);
             finish(done && sel);
         }
     }

@@ -448,6 +448,9 @@ void runRenderer(int ns, int tx, int ty) {
         part.world = world;
         part.local_rows = (int)d.fb_rows;
         if (c.opt.counters) HIP_CHECK(hipMemsetAsync(d.d_counters, 0, sizeof(RtCounters), d.stream));
+        // Poison the device framebuffer (all-ones = NaN) outside the timed region: every pixel is written exactly once per
+        // frame, so a pixel the work distribution lost shows up as NaN instead of as last frame's (correct-looking) value.
+        if (d.fb_rows > 0) HIP_CHECK(hipMemsetAsync(d.d_fb, 0xFF, d.fb_rows * row_bytes, d.stream));
         HIP_CHECK(hipEventRecord(d.ev_start, d.stream));
         if (c.max_depth <= 0) {
             HIP_CHECK(hipMemsetAsync(d.d_fb, 0, d.fb_rows * row_bytes, d.stream));     // loop of kernels.cu:402 never runs

@@ -43,6 +43,20 @@ def test_random_spheres_bit_exact(rt, O, nx, ny, ns, variant):
     assert st.rays == cnt.rays
 
 
+def test_two_dispatch_cost_ordered_frame_bit_exact(rt, O):
+    """ns >= 8 with the reference stream renders a frame in two dispatches (2 samples, cost ordering, resume: DESIGN.md 3.2)
+    with chain waves, 17 cost lists and boosts.  Same bits as the oracle and as the single-dispatch work orders, every pixel
+    written (the device framebuffer is NaN-poisoned before each frame), ray count equal to the oracle's."""
+    nx, ny, ns = 480, 320, 12
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50, counters=True)
+    for variant in (0, 1 << 24, 3 << 24, 7 << 27):     # two dispatches; tile-major and centre-ray single dispatch; boost off
+        got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, counters=1, variant=variant)
+        assert not np.isnan(got).any(), variant
+        assert np.array_equal(_bits(got), _bits(ref)), (variant, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert st.rays == cnt.rays, variant
+
+
 def test_random_spheres_options_bit_exact(rt, O):
     """Russian roulette, constant sky, counter RNG, shallow depth: each option against the oracle."""
     nx, ny, ns = 96, 64, 4

@@ -1,5 +1,6 @@
-"""Condenses the rocprofv3 CSVs of tools/profile.sh into one text summary (kernel stats + per-dispatch
-counter averages of the render kernel)."""
+"""Condenses the rocprofv3 CSVs of tools/profile.sh into one text summary (kernel stats + counter totals of the
+render kernel PER FRAME: the reference-stream mode renders a frame in two dispatches of the same kernel, so the
+counters of a frame's dispatches are added)."""
 import csv
 import glob
 import os
@@ -32,22 +33,32 @@ for f, r in rows("*kernel_trace.csv"):
 for name, d in dur.items():
     print(name[:80], "calls", len(d), "avg ms %.3f min %.3f max %.3f" % (sum(d) / len(d), min(d), max(d)), meta[name])
 
-print("== PMC counters: mean per dispatch of the render kernel ==")
+for name, d in dur.items():
+    per_frame = 2 if any("k_order_by_cost" in r.get("Kernel_Name", "") for f, r in rows("*kernel_trace.csv")) else 1
+    frames = max(len(d) // per_frame, 1)
+    print("render kernel time per frame: %.3f ms (%d dispatches per frame, %d frames)" % (sum(d) / frames, per_frame, frames))
+
+print("== PMC counters: total per FRAME of the render kernel (dispatches of one frame added) ==")
 acc = defaultdict(list)
+two_phase = False
 for f, r in rows("*counter_collection.csv"):
+    two_phase = two_phase or "k_order_by_cost" in r.get("Kernel_Name", "")
     if "k_render" in r.get("Kernel_Name", ""):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-vals = {k: sum(v) / len(v) for k, v in acc.items()}
+per_frame = 2 if two_phase else 1
+vals = {k: sum(v) / max(len(v) // per_frame, 1) for k, v in acc.items()}
 for k in sorted(vals):
-    print("%-28s %.6g   (n=%d)" % (k, vals[k], len(acc[k])))
+    print("%-28s %.6g   (%d dispatches, %d per frame)" % (k, vals[k], len(acc[k]), per_frame))
 g = vals.get
 if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
     print("VALU insts per wave            %.4g" % (g("SQ_INSTS_VALU") / g("SQ_WAVES")))
 if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
     print("VALU lane utilisation          %.3f  (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)... see DESIGN.md)" %
           (g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))))
-if g("SQ_ACTIVE_INST_VALU") and g("SQ_BUSY_CYCLES"):
-    print("VALU busy (ACTIVE_INST_VALU*4/BUSY_CYCLES/SIMDs-per-SE..) raw ratio %.4g" % (g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CYCLES")))
+if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    print("kernel cycles per frame (GRBM_GUI_ACTIVE / 8 XCDs) %.4g ; VALUBusy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = %.3f" %
+          (cyc, g("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * cyc)))
 if g("FETCH_SIZE") is not None:
     print("FETCH_SIZE KB %.6g  -> x2 gfx950 correction = %.6g KB" % (g("FETCH_SIZE"), 2 * g("FETCH_SIZE")))
 if g("WRITE_SIZE") is not None:
