@@ -318,7 +318,9 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
     }
 }
 
-__global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing) {
+// TRAV 0: thresholded while-while (default); TRAV 1: classic while-while (all lanes descend to a leaf, then all test their leaf)
+template <int TRAV>
+__global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
@@ -341,6 +343,10 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
     bool have_pixel = false, exhausted = false;
     TravStats st = { 0, 0 };
     uint32_t nrays = 0, nshadow = 0;
+    // diagnostics (P.dbg): cycles and active lanes per phase, per wave; summed over the waves at the end
+    unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
+    unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
+    const bool dbg = P.dbg != nullptr;
 
     auto start_sample = [&]() {                                      // kernels.cu:549-555, 397-398
         if (P.rng_mode == RT_RNG_COUNTER) rng = sample_seed(pixelId, (uint32_t)s);
@@ -360,6 +366,8 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
 
     while (true) {
         // ================= PROCESS: lanes without a running traversal =======================================
+        unsigned long long c0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (dbg) { const int n_ = (int)__popcll(__ballot(have_pixel && J.idx == 0)); g_act[0] += (unsigned long long)n_; g_it[0] += n_ ? 1ull : 0ull; }
         if (have_pixel && J.idx == 0) {
             bool path_done = false;
             bool next_ray = false;                                   // continue the path with a new closest-hit job
@@ -467,6 +475,7 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
             }
         }
 
+        if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[0] += c1 - c0; c0 = c1; }
         // ================= refill idle lanes from the global pixel queue ======================================
         while (!exhausted) {
             const unsigned long long need = __ballot(!have_pixel);
@@ -496,62 +505,145 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
             }
         }
         if (__ballot(have_pixel) == 0ull) break;
+        if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[1] += c1 - c0; c0 = c1; }
 
         // ================= TRAVERSE ================================================================================
         // at least once; keep going while enough lanes have nodes left (the others wait for the next PROCESS phase)
-        do {
-            // descend: internal nodes (kernels.cu:162-195)
-            while (have_pixel && J.idx != 0 && (uint32_t)J.idx < P.first_leaf) {
-                const int idx2 = J.idx << 1;
-                const float4* n = P.bvh4 + (size_t)J.idx * 3;
-                const float4 na = n[0], nb = n[1], nc = n[2];
-                st.nodes++;
-                const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest);
-                const bool traverseLeft = leftHit < J.closest;
-                const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest);
-                const bool traverseRight = rightHit < J.closest;
-                const bool swap = rightHit < leftHit;
-                if (traverseLeft && traverseRight) {
-                    J.idx = idx2 + (swap ? 1 : 0);
-                    J.bitStack = (J.bitStack << 1) + 1;
-                } else if (traverseLeft || traverseRight) {
-                    J.idx = idx2 + (swap ? 1 : 0);
-                    J.bitStack = J.bitStack << 1;
+        if (TRAV == 0) {
+            // Thresholded while-while.  One wave step is EITHER a node step (kernels.cu:162-195) for the lanes at an
+            // internal node OR the leaf loop (kernels.cu:196-214) for the lanes at a leaf.  Classic while-while runs node
+            // steps until EVERY lane sits on a leaf: measured 17.7 of 64 lanes busy per node step (tools/mesh_debug.py),
+            // because descents between two leaves take 1..30 steps.  Here the leaf loop runs as soon as `leaf_thr` lanes
+            // wait at a leaf (or no lane is at a node): lanes waiting for the slowest descent are capped at leaf_thr.
+            // Every ray still sees the reference's own sequence of node visits and triangle tests.
+            do {
+                const bool act = have_pixel && J.idx != 0;
+                const bool at_node = act && (uint32_t)J.idx < P.first_leaf;
+                const int n_node = (int)__popcll(__ballot(at_node));
+                const int n_leaf = (int)__popcll(__ballot(act && !at_node));
+                if (n_node > 0 && n_leaf < leaf_thr) {
+                    if (dbg) { g_act[2] += (unsigned long long)n_node; g_it[2]++; }
+                    if (at_node) {
+                        const int idx2 = J.idx << 1;
+                        const float4* n = P.bvh4 + (size_t)J.idx * 3;
+                        const float4 na = n[0], nb = n[1], nc = n[2];
+                        st.nodes++;
+                        const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest);
+                        const bool traverseLeft = leftHit < J.closest;
+                        const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest);
+                        const bool traverseRight = rightHit < J.closest;
+                        const bool swap = rightHit < leftHit;
+                        if (traverseLeft || traverseRight) {
+                            J.idx = idx2 + (swap ? 1 : 0);
+                            J.bitStack = (J.bitStack << 1) + ((traverseLeft && traverseRight) ? 1u : 0u);
+                        } else {
+                            const int m = __ffs((int)J.bitStack) - 1;    // pop_bitstack, kernels.cu:148-152
+                            J.bitStack = (J.bitStack >> m) ^ 1u;
+                            J.idx = (J.idx >> m) ^ 1;
+                        }
+                    }
+                    if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[2] += c1 - c0; c0 = c1; }
                 } else {
-                    const int m = __ffs((int)J.bitStack) - 1;        // pop_bitstack, kernels.cu:148-152
-                    J.bitStack = (J.bitStack >> m) ^ 1u;
-                    J.idx = (J.idx >> m) ^ 1;
+                    if (dbg) { g_act[3] += (unsigned long long)n_leaf; g_it[3]++; }
+                    if (act && !at_node) {
+                        const uint32_t first = ((uint32_t)J.idx - P.first_leaf) * P.nppl;
+                        bool occluded = false;
+                        for (uint32_t k = 0; k < P.nppl; k++) {
+                            const float4* pt = reinterpret_cast<const float4*>(P.tris + first + k);
+                            const float4 a = pt[0], b = pt[1];
+                            if (isinf(a.x)) break;                       // kernels.cu:202 sentinel
+                            const float cx = pt[2].x;
+                            float u, v;
+                            st.tests++;
+                            const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
+                            if (hitT < J.closest) {
+                                if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
+                                J.closest = hitT;
+                                J.triId = first + k;
+                                J.hu = u; J.hv = v;
+                            }
+                        }
+                        if (occluded) {
+                            J.closest = 0.0f;
+                            J.idx = 0;
+                        } else {
+                            const int m = __ffs((int)J.bitStack) - 1;
+                            J.bitStack = (J.bitStack >> m) ^ 1u;
+                            J.idx = (J.idx >> m) ^ 1;
+                        }
+                    }
+                    if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[3] += c1 - c0; c0 = c1; }
                 }
-            }
-            // leaf (kernels.cu:196-214)
-            if (have_pixel && J.idx != 0) {
-                const uint32_t first = ((uint32_t)J.idx - P.first_leaf) * P.nppl;
-                bool occluded = false;
-                for (uint32_t k = 0; k < P.nppl; k++) {
-                    const float4* pt = reinterpret_cast<const float4*>(P.tris + first + k);
-                    const float4 a = pt[0], b = pt[1];
-                    if (isinf(a.x)) break;                           // kernels.cu:202 sentinel
-                    const float cx = pt[2].x;
-                    float u, v;
-                    st.tests++;
-                    const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
-                    if (hitT < J.closest) {
-                        if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
-                        J.closest = hitT;
-                        J.triId = first + k;
-                        J.hu = u; J.hv = v;
+                // back to PROCESS when enough lanes have a finished traversal to consume (or nothing is left to traverse);
+                // lanes without a pixel (end of the frame) do not count, so the tail does not bounce between the phases
+            } while (__ballot(have_pixel && J.idx != 0) != 0ull && (int)__popcll(__ballot(have_pixel && J.idx == 0)) < 64 - min_traversing);
+        } else {
+            do {
+                // descend: internal nodes (kernels.cu:162-195)
+                for (;;) {
+                    const bool at_node = have_pixel && J.idx != 0 && (uint32_t)J.idx < P.first_leaf;
+                    const unsigned long long node_m = __ballot(at_node);
+                    if (node_m == 0ull) break;
+                    if (dbg) { g_act[2] += (unsigned long long)__popcll(node_m); g_it[2]++; }
+                    if (!at_node) continue;
+                    const int idx2 = J.idx << 1;
+                    const float4* n = P.bvh4 + (size_t)J.idx * 3;
+                    const float4 na = n[0], nb = n[1], nc = n[2];
+                    st.nodes++;
+                    const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest);
+                    const bool traverseLeft = leftHit < J.closest;
+                    const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest);
+                    const bool traverseRight = rightHit < J.closest;
+                    const bool swap = rightHit < leftHit;
+                    if (traverseLeft && traverseRight) {
+                        J.idx = idx2 + (swap ? 1 : 0);
+                        J.bitStack = (J.bitStack << 1) + 1;
+                    } else if (traverseLeft || traverseRight) {
+                        J.idx = idx2 + (swap ? 1 : 0);
+                        J.bitStack = J.bitStack << 1;
+                    } else {
+                        const int m = __ffs((int)J.bitStack) - 1;        // pop_bitstack, kernels.cu:148-152
+                        J.bitStack = (J.bitStack >> m) ^ 1u;
+                        J.idx = (J.idx >> m) ^ 1;
                     }
                 }
-                if (occluded) {
-                    J.closest = 0.0f;
-                    J.idx = 0;
-                } else {
-                    const int m = __ffs((int)J.bitStack) - 1;
-                    J.bitStack = (J.bitStack >> m) ^ 1u;
-                    J.idx = (J.idx >> m) ^ 1;
+                if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[2] += c1 - c0; c0 = c1; }
+                if (dbg) { g_act[3] += (unsigned long long)__popcll(__ballot(have_pixel && J.idx != 0)); g_it[3]++; }
+                // leaf (kernels.cu:196-214)
+                if (have_pixel && J.idx != 0) {
+                    const uint32_t first = ((uint32_t)J.idx - P.first_leaf) * P.nppl;
+                    bool occluded = false;
+                    for (uint32_t k = 0; k < P.nppl; k++) {
+                        const float4* pt = reinterpret_cast<const float4*>(P.tris + first + k);
+                        const float4 a = pt[0], b = pt[1];
+                        if (isinf(a.x)) break;                           // kernels.cu:202 sentinel
+                        const float cx = pt[2].x;
+                        float u, v;
+                        st.tests++;
+                        const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
+                        if (hitT < J.closest) {
+                            if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
+                            J.closest = hitT;
+                            J.triId = first + k;
+                            J.hu = u; J.hv = v;
+                        }
+                    }
+                    if (occluded) {
+                        J.closest = 0.0f;
+                        J.idx = 0;
+                    } else {
+                        const int m = __ffs((int)J.bitStack) - 1;
+                        J.bitStack = (J.bitStack >> m) ^ 1u;
+                        J.idx = (J.idx >> m) ^ 1;
+                    }
                 }
-            }
-        } while (__popcll(__ballot(have_pixel && J.idx != 0)) >= min_traversing);
+                if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[3] += c1 - c0; c0 = c1; }
+            } while (__popcll(__ballot(have_pixel && J.idx != 0)) >= min_traversing);
+        }
+    }
+    if (dbg && (threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 4; k++) { atomicAdd(P.dbg + k, g_cyc[k]); atomicAdd(P.dbg + 4 + k, g_act[k]); atomicAdd(P.dbg + 8 + k, g_it[k]); }
+        atomicAdd(P.dbg + 12, 1ull);
     }
 
     if (P.counters) {
@@ -566,7 +658,9 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
 
 // variant: bits 0..7  0 = persistent state-machine kernel (default), 1 = first kernel (one tile per wave);
 //          bits 8..15 workgroups per CU of the persistent kernel (0 = default 5);
-//          bits 16..23 keep traversing while at least this many lanes have nodes left (0 = default 40).
+//          bits 16..23 keep traversing while at least this many lanes have nodes left (0 = default: 24, classic 40);
+//          bits 24..25 traversal of the persistent kernel: 0 = thresholded while-while (default), 1 = classic while-while;
+//          bits 26..31 leaf threshold of the former (0 = default 24).
 hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream) {
     if ((variant & 0xFF) == 1) {
         const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
@@ -592,8 +686,12 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
+    const bool classic = ((variant >> 24) & 3) == 1;
     int min_traversing = (variant >> 16) & 0xFF;
-    if (min_traversing == 0) min_traversing = kMinTraversing;
-    hipLaunchKernelGGL(k_render_mesh_queue, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing);
+    if (min_traversing == 0) min_traversing = classic ? kMinTraversing : 24;    // measured: 16 -> 409, 20 -> 435, 24 -> 446, 32 -> 429 Msamples/s
+    int leaf_thr = (variant >> 26) & 0x3F;
+    if (leaf_thr == 0) leaf_thr = 24;                                         // measured: 8 -> 385, 16 -> 427, 24 -> 430-446, 31 -> 433
+    if (classic) hipLaunchKernelGGL(k_render_mesh_queue<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing, leaf_thr);
+    else hipLaunchKernelGGL(k_render_mesh_queue<0>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing, leaf_thr);
     return hipGetLastError();
 }

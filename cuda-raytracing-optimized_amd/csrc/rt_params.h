@@ -83,6 +83,7 @@ struct RtMeshParams {
     rt_vec3 lightColor;
     RtCounters* counters;
     uint32_t* queue;
+    unsigned long long* dbg;    // diagnostics (RT_WAVE_DEBUG): 16 phase counters summed over all waves, or nullptr
 };
 
 // LDS the sphere kernel needs for a scene of n spheres with `threads` threads per workgroup.

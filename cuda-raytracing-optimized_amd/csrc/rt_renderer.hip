@@ -507,6 +507,12 @@ void runRenderer(int ns, int tx, int ty) {
             p.light = c.opt.light; p.lightColor = c.opt.lightColor;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
             p.queue = d.d_queue;
+            if (getenv("RT_WAVE_DEBUG")) {                           // diagnostics: phase cycle / lane counters -> file
+                const size_t dbg_bytes = (size_t)65536 * 8 * sizeof(unsigned long long);
+                if (!d.d_wave_dbg) HIP_CHECK(hipMalloc((void**)&d.d_wave_dbg, dbg_bytes));
+                HIP_CHECK(hipMemsetAsync(d.d_wave_dbg, 0, dbg_bytes, d.stream));
+                p.dbg = d.d_wave_dbg;
+            }
             HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_mesh_fast(p, c.opt.variant, d.stream)
                                              : rt_launch_mesh_parity(p, c.opt.variant, d.stream));
             launches++;
@@ -543,7 +549,7 @@ void runRenderer(int ns, int tx, int ty) {
             std::vector<unsigned long long> h((size_t)65536 * 8);
             HIP_CHECK(hipMemcpy(h.data(), d.d_wave_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE* f = fopen(getenv("RT_WAVE_DEBUG"), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
-            if (d.d_px_state) {                                      // per-pixel time line of the second phase (see finish())
+            if (d.d_px_state && c.is_spheres) {                      // per-pixel time line of the second phase (see finish())
                 std::vector<float> px((size_t)d.fb_rows * c.nx * 4);
                 HIP_CHECK(hipMemcpy(px.data(), d.d_px_state, px.size() * sizeof(float), hipMemcpyDeviceToHost));
                 const std::string path = std::string(getenv("RT_WAVE_DEBUG")) + ".px";

@@ -31,7 +31,7 @@ def _render_gpu(rt, hm, mats, cam, nx, ny, ns, depth, **opts):
     return out, st
 
 
-@pytest.mark.parametrize("variant", [0, 1, (1 << 8), (8 << 8)])       # 0 = persistent state machine, 1 = tile per wave; bits 8.. = WGs per CU
+@pytest.mark.parametrize("variant", [0, 1, (1 << 8), (8 << 8), (1 << 24), (1 << 24) + (20 << 16)])   # 0 = persistent state machine (unified step), 1 = tile per wave; bits 8.. = WGs per CU; 1<<24 = while-while
 def test_mesh_no_nee_bit_exact(rt, O, stair, variant):
     hm, mats = stair
     nx, ny, ns = 96, 120, 2
@@ -86,9 +86,10 @@ def test_mesh_variants_agree_bit_for_bit_with_nee(rt, stair):
     nx, ny, ns = 80, 96, 3
     cam = rt.staircase_camera(nx, ny)
     a, sa = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1, variant=0)
-    b, sb = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1, variant=1)
-    assert np.array_equal(_bits(a), _bits(b))
-    assert (sa.rays, sa.node_visits, sa.prim_tests) == (sb.rays, sb.node_visits, sb.prim_tests)
+    for variant in (1, 1 << 24):                # tile per wave; persistent kernel with while-while traversal
+        b, sb = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1, variant=variant)
+        assert np.array_equal(_bits(a), _bits(b)), variant
+        assert (sa.rays, sa.node_visits, sa.prim_tests) == (sb.rays, sb.node_visits, sb.prim_tests), variant
 
 
 def test_mesh_textures_bit_exact(rt, O, stair):
