@@ -320,11 +320,24 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
 
 // TRAV 0: thresholded while-while (default); TRAV 1: classic while-while (all lanes descend to a leaf, then all test their leaf)
 template <int TRAV>
-__global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
+__global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
     const float eps = P.t_min;
+    // leaf phase of TRAV 0: per-wave LDS scratch and this lane's fixed role in a pair round (ray j / nppl, triangle j % nppl)
+    __shared__ uint32_t s_owner[kThreads], s_sent[kThreads];
+    __shared__ unsigned long long s_best[kThreads];
+    __shared__ float2 s_uv[kThreads];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* w_owner = s_owner + (threadIdx.x & ~63u);
+    uint32_t* w_sent = s_sent + (threadIdx.x & ~63u);
+    unsigned long long* w_best = s_best + (threadIdx.x & ~63u);
+    float2* w_uv = s_uv + (threadIdx.x & ~63u);
+    const int pair_per = (TRAV == 0 && P.nppl >= 1u && P.nppl <= 16u) ? (int)(64u / P.nppl) : 0;     // rays per pair round
+    const uint32_t pair_r = pair_per ? lane / P.nppl : 0u;
+    const uint32_t pair_k = pair_per ? lane - pair_r * P.nppl : 0u;
+    const bool pair_ok = pair_per && (int)pair_r < pair_per;
     const f3 lightC = ld3(P.light.center);
     const float lightR = P.light.radius;
     float* fbf = reinterpret_cast<float*>(P.fb);
@@ -545,6 +558,103 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
                     if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[2] += c1 - c0; c0 = c1; }
                 } else {
                     if (dbg) { g_act[3] += (unsigned long long)n_leaf; g_it[3]++; }
+                    if (pair_per > 0) {
+                        // (ray, triangle) pairs: the <= leaf_thr lanes at a leaf have nppl triangles each; tested one triangle
+                        // per lane and nppl steps they would keep n_leaf of 64 lanes busy.  Instead lane j of a round takes
+                        // triangle j % nppl of the (j / nppl)-th waiting ray: ray fetched with ds_bpermute, result folded into
+                        // the owner's slot with one 64-bit LDS atomicMin.  The reference's loop (kernels.cu:196-214) returns the
+                        // lexicographic minimum of (t, k) over the triangles before the first sentinel that hit below `closest`
+                        // (its running t_max only rejects what the minimum rejects too); a shadow ray stops at the FIRST k that
+                        // hits.  Both are what min(key) below is, key = t_bits << 32 | k (t > 0) resp. k for shadow rays.
+                        const bool at_leaf = act && !at_node;
+                        const unsigned long long leaf_m = __ballot(at_leaf);
+                        const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(leaf_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)leaf_m, 0u));
+                        if (at_leaf) w_owner[my_rank] = lane;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t packed = (uint32_t)J.idx | (J.shadow ? 0x80000000u : 0u);
+                        unsigned long long my_best = ~0ull;              // owner side: result of my leaf
+                        float my_u = 0.0f, my_v = 0.0f;
+                        for (int base = 0; base < n_leaf; base += pair_per) {
+                            const int r = base + (int)pair_r;
+                            const bool pv = pair_ok && r < n_leaf;
+                            const uint32_t owner = pv ? w_owner[r] : lane;
+                            if (pv) { w_sent[owner] = 0xFFFFFFFFu; w_best[owner] = ~0ull; }      // same value from every pair lane of the owner
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const int src = (int)(owner << 2);
+                            const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.x)));
+                            const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.y)));
+                            const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.z)));
+                            const float dx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.d.x)));
+                            const float dy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.d.y)));
+                            const float dz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.d.z)));
+                            const float o_closest = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.closest)));
+                            const uint32_t o_packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)packed);
+                            const bool o_shadow = (o_packed & 0x80000000u) != 0u;
+                            const uint32_t slot = ((o_packed & 0x7FFFFFFFu) - P.first_leaf) * P.nppl + pair_k;
+                            float4 ta = make_float4(0, 0, 0, 0), tb = ta;
+                            float tcx = 0.0f;
+                            bool sent = false;
+                            if (pv) {
+                                const float4* pt = reinterpret_cast<const float4*>(P.tris + slot);
+                                ta = pt[0]; tb = pt[1]; tcx = pt[2].x;
+                                sent = isinf(ta.x);                      // kernels.cu:202 sentinel
+                                if (sent) atomicMin(&w_sent[owner], pair_k);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            bool reached = false, hit = false;
+                            float u = 0.0f, v = 0.0f;
+                            unsigned long long key = ~0ull;
+                            if (pv) {
+                                reached = pair_k < w_sent[owner];        // the loop breaks at the first sentinel
+                                if (reached) {
+                                    Ray pr;
+                                    pr.o = F3(ox, oy, oz); pr.d = F3(dx, dy, dz); pr.inv = F3(0, 0, 0);
+                                    const float hitT = triangle_hit(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tcx), pr, eps, o_closest, u, v);
+                                    hit = hitT < o_closest;
+                                    if (hit) {
+                                        key = o_shadow ? (unsigned long long)pair_k
+                                                       : (((unsigned long long)__float_as_uint(hitT) << 32) | (unsigned long long)pair_k);
+                                        atomicMin(&w_best[owner], key);
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            if (pv) {
+                                const unsigned long long best = w_best[owner];
+                                // tests the reference executes: every reached triangle; a shadow ray stops after its first hit
+                                if (reached && (!o_shadow || best == ~0ull || (unsigned long long)pair_k <= best)) st.tests++;
+                                if (hit && key == best) w_uv[owner] = make_float2(u, v);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            if (at_leaf && (int)my_rank >= base && (int)my_rank < base + pair_per) {
+                                my_best = w_best[lane];
+                                const float2 uv = w_uv[lane];
+                                my_u = uv.x; my_v = uv.y;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (at_leaf) {
+                            if (my_best != ~0ull && J.shadow) {          // any-hit: hitBvh returns 0.0f (kernels.cu:205)
+                                J.closest = 0.0f;
+                                J.idx = 0;
+                            } else {
+                                if (my_best != ~0ull) {
+                                    J.closest = __uint_as_float((uint32_t)(my_best >> 32));
+                                    J.triId = ((uint32_t)J.idx - P.first_leaf) * P.nppl + (uint32_t)(my_best & 0xFFFFFFFFull);
+                                    J.hu = my_u; J.hv = my_v;
+                                }
+                                const int m = __ffs((int)J.bitStack) - 1;
+                                J.bitStack = (J.bitStack >> m) ^ 1u;
+                                J.idx = (J.idx >> m) ^ 1;
+                            }
+                        }
+                    } else
                     if (act && !at_node) {
                         const uint32_t first = ((uint32_t)J.idx - P.first_leaf) * P.nppl;
                         bool occluded = false;
@@ -660,7 +770,7 @@ __global__ void __launch_bounds__(kThreads, 5) k_render_mesh_queue(const RtMeshP
 //          bits 8..15 workgroups per CU of the persistent kernel (0 = default 5);
 //          bits 16..23 keep traversing while at least this many lanes have nodes left (0 = default: 24, classic 40);
 //          bits 24..25 traversal of the persistent kernel: 0 = thresholded while-while (default), 1 = classic while-while;
-//          bits 26..31 leaf threshold of the former (0 = default 24).
+//          bits 26..31 leaf threshold of the former (0 = default 16).
 hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream) {
     if ((variant & 0xFF) == 1) {
         const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
@@ -673,7 +783,7 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 5;      // launch bound: 5 waves per SIMD (96 VGPRs); 6 gave the same rate, 8 spills
+    if (wg_per_cu == 0) wg_per_cu = (((variant >> 24) & 3) == 1) ? 5 : 4;   // = the launch bounds (96 / 128 VGPRs); the pair rounds spill at 96      // launch bound: 5 waves per SIMD (96 VGPRs); 6 gave the same rate, 8 spills
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + kThreads - 1) / kThreads;
@@ -690,7 +800,7 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     int min_traversing = (variant >> 16) & 0xFF;
     if (min_traversing == 0) min_traversing = classic ? kMinTraversing : 24;    // measured: 16 -> 409, 20 -> 435, 24 -> 446, 32 -> 429 Msamples/s
     int leaf_thr = (variant >> 26) & 0x3F;
-    if (leaf_thr == 0) leaf_thr = 24;                                         // measured: 8 -> 385, 16 -> 427, 24 -> 430-446, 31 -> 433
+    if (leaf_thr == 0) leaf_thr = 16;                                         // measured (pair rounds): 12 -> 447, 16 -> 467, 24 -> 430, 31 -> 409 Msamples/s
     if (classic) hipLaunchKernelGGL(k_render_mesh_queue<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing, leaf_thr);
     else hipLaunchKernelGGL(k_render_mesh_queue<0>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing, leaf_thr);
     return hipGetLastError();
