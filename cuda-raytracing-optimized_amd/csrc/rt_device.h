@@ -260,8 +260,12 @@ __device__ __forceinline__ void slab(float bmin, float bmax, float o, float invD
     float t0 = (bmin - o) * invD;
     float t1 = (bmax - o) * invD;
     if (invD < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-    t_min = t0 > t_min ? t0 : t_min;
-    t_max = t1 < t_max ? t1 : t_max;
+    // `t0 > t_min ? t0 : t_min` / `t1 < t_max ? t1 : t_max` as ONE v_max_f32 / v_min_f32 each (IEEE maxNum/minNum) instead of
+    // compare + select: t_min (>= 0.001) and t_max (a hit distance or FLT_MAX) are never NaN, so a NaN t0/t1 (0 * inf on a
+    // slab plane) leaves them unchanged in both forms; the only other difference, the sign of a zero t_max, cannot reach a
+    // result (t_max is only compared, against values >= 0.001).  Checked bit for bit by the hit_bbox probes.
+    t_min = fmaxf(t0, t_min);
+    t_max = fminf(t1, t_max);
 }
 
 __device__ __forceinline__ float hit_bbox_dist(f3 bmin, f3 bmax, const Ray& r, float t_max) {  // intersections.h:25-41

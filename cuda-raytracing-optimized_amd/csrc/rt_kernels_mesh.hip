@@ -319,7 +319,7 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
 }
 
 // TRAV 0: thresholded while-while (default); TRAV 1: classic while-while (all lanes descend to a leaf, then all test their leaf)
-template <int TRAV>
+template <int TRAV, bool DBG>
 __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     // diagnostics (P.dbg): cycles and active lanes per phase, per wave; summed over the waves at the end
     unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
-    const bool dbg = P.dbg != nullptr;
+    const bool dbg = DBG && P.dbg != nullptr;       // DBG = false: the diagnostics (and their SGPR pressure) compile away
 
     auto start_sample = [&]() {                                      // kernels.cu:549-555, 397-398
         if (P.rng_mode == RT_RNG_COUNTER) rng = sample_seed(pixelId, (uint32_t)s);
@@ -801,7 +801,13 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     if (min_traversing == 0) min_traversing = classic ? kMinTraversing : 24;    // measured: 16 -> 409, 20 -> 435, 24 -> 446, 32 -> 429 Msamples/s
     int leaf_thr = (variant >> 26) & 0x3F;
     if (leaf_thr == 0) leaf_thr = 16;                                         // measured (pair rounds): 12 -> 447, 16 -> 467, 24 -> 430, 31 -> 409 Msamples/s
-    if (classic) hipLaunchKernelGGL(k_render_mesh_queue<1>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing, leaf_thr);
-    else hipLaunchKernelGGL(k_render_mesh_queue<0>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, stride, min_traversing, leaf_thr);
+    const dim3 grid((unsigned)blocks), block(kThreads);
+    if (classic) {
+        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<1, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<1, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+    } else {
+        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<0, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+    }
     return hipGetLastError();
 }
