@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // therefore traces a ray in (almost) every iteration until the queue is empty; which lane renders which pixel is
 // irrelevant to the result because the seed is a function of the global pixel id only.
 
-template <bool LEGACY>
+template <bool LEGACY, bool DBG>
 __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
                                                                    int cull, int boost, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -816,8 +816,10 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     bool exhausted = false;             // wave-uniform: the global queue is empty
     uint32_t pool_next = 0, pool_end = 0;   // wave-uniform: the wave's reserved queue positions [pool_next, pool_end)
     float* fbf = reinterpret_cast<float*>(P.fb);
-    // diagnostics (only when P.wave_dbg): 100 MHz time stamps and iteration counts of this wave
-    const unsigned long long dbg_t0 = P.wave_dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // diagnostics (only when wdbg, and only in the DBG instantiation: in the production one they compile away, with
+    // their SGPR pressure): 100 MHz time stamps and iteration counts of this wave
+    unsigned long long* const wdbg = DBG ? P.wave_dbg : nullptr;
+    const unsigned long long dbg_t0 = wdbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
     float dbg_grab = 0.0f, dbg_p1 = 0.0f;                           // this lane's pixel: time it was grabbed, rays of phase 1
@@ -843,7 +845,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                     float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * K + (uint32_t)chunk) * 3;
                     dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
                 }
-                if (P.wave_dbg) {
+                if (wdbg) {
                     dbg_maxpix = max(dbg_maxpix, pix_rays);
                     if (P.phase == 2)                                // per-pixel time line: (grabbed, finished) in ms, rays in total, rays in phase 1
                         P.px_state[(size_t)lr * P.nx + L.i] = make_float4(dbg_grab, (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f, (float)pix_rays, dbg_p1);
@@ -947,7 +949,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
                         L.col = F3(st4.x, st4.y, st4.z);
                         L.s = P.s_split;
                         pix_rays = P.px_rays[px];
-                        if (P.wave_dbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
+                        if (wdbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
                         start_sample(P, L);
                     }
                     have_pixel = true;
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         }
         const unsigned long long live_now = __ballot(have_pixel);
         if (live_now == 0ull) break;                                 // wave-uniform exit: idle lanes stay to help
-        if (P.wave_dbg) {
+        if (wdbg) {
             if (exhausted && dbg_tex == 0ull) dbg_tex = __builtin_amdgcn_s_memrealtime();
             dbg_iters++;
             if (__popcll(live_now) <= sparse_max) { dbg_coop_iters++; dbg_coop_rays += (uint32_t)__popcll(live_now); }   // sparse-form iterations / rays
@@ -999,9 +1001,9 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
         atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 16ull);     // lane-parallel phase-1 tests executed
     }
-    if (P.wave_dbg) atomicMax(P.wave_dbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
-    if (P.wave_dbg && (threadIdx.x & 63) == 0) {
-        unsigned long long* w = P.wave_dbg + ((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 8;
+    if (wdbg) atomicMax(wdbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
+    if (wdbg && (threadIdx.x & 63) == 0) {
+        unsigned long long* w = wdbg + ((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 8;
         w[0] = dbg_t0; w[1] = dbg_tex; w[2] = __builtin_amdgcn_s_memrealtime();
         w[3] = dbg_iters; w[4] = dbg_coop_iters; w[5] = dbg_coop_rays;
         w[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
@@ -1053,7 +1055,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     const int cb_bits = (variant >> 16) & 0xFF;
     const bool legacy = cb_bits != 0 && cb_bits != 255;
     const void* kern = (kind == 1) ? (legacy ? reinterpret_cast<const void*>(k_render_spheres_tiles<true>) : reinterpret_cast<const void*>(k_render_spheres_tiles<false>))
-                                   : (legacy ? reinterpret_cast<const void*>(k_render_spheres_queue<true>) : reinterpret_cast<const void*>(k_render_spheres_queue<false>));
+                                   : (legacy ? reinterpret_cast<const void*>(k_render_spheres_queue<true, false>) : reinterpret_cast<const void*>(k_render_spheres_queue<false, false>));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_spheres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1099,8 +1101,10 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // (measured on C2: every third / 10 / 3 is the optimum of a flat basin)
     const int chain_cfg = 3 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
     auto launch_queue = [&](const RtSphereParams& q, int classified) {
-        if (legacy) hipLaunchKernelGGL(k_render_spheres_queue<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
-        else hipLaunchKernelGGL(k_render_spheres_queue<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
+        const dim3 grid((unsigned)blocks), block(kThreads);
+        if (legacy) hipLaunchKernelGGL((k_render_spheres_queue<true, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
+        else if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<false, true>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
+        else hipLaunchKernelGGL((k_render_spheres_queue<false, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
         return hipGetLastError();
     };
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
