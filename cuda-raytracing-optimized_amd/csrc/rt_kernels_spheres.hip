@@ -47,7 +47,9 @@ namespace {
 constexpr int kWavesPerWg = 4;              // 4 waves side by side: a 32 x 8 pixel tile per workgroup
 constexpr int kThreads = 64 * kWavesPerWg;
 constexpr int kPassGroups = 16;                                  // groups per pair-list pass: at most 64 x 16 pairs
-constexpr int kWaveScratch = 64 * 32 + 64 * 8 + (64 * kPassGroups + 64) * 2;     // per wave: ray table, best-hit keys, (lane, group) pair list
+constexpr int kCandCap = 192;                                    // candidate list of the pair scan: 64 carried + up to 128 new per round
+constexpr int kWaveScratchPairs = 64 * 32 + 64 * 8 + (64 * kPassGroups + 64) * 2;     // per wave: ray table, best-hit keys, (lane, group) pair list
+constexpr int kWaveScratch = kWaveScratchPairs + kCandCap * 4 + 16;             // + (owner, slot) candidate list and its counter
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     const int stripe = lr / pt.stripe_rows;
@@ -280,7 +282,21 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     float4* w_ray = reinterpret_cast<float4*>(W);                               // 64 x 2 float4
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);
+    uint32_t* w_cand = reinterpret_cast<uint32_t*>(W + kWaveScratchPairs);
+    uint32_t* w_ccnt = w_cand + kCandCap;
     const float t_min = P.t_min;
+    if (lane == 0) *w_ccnt = 0u;                                     // published by the first fence below
+
+    // exact resolution of ONE candidate (owner ray, sphere slot) by this lane: the literal sphereHit tail, merged into the
+    // owner's slot with the (t, original index) key.  t_max = FLT_MAX: a root beyond the owner's current best loses the min anyway.
+    auto resolve = [&](uint32_t e) {
+        const int owner = (int)(e >> 16), k = (int)(e & 0xFFFFu);
+        const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
+        const float t = sphere_hit_exact(S.sph[sidx(k)], F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, t_min, FLT_MAX);
+        const int o = S.orig[k];
+        if (o != 0x7fffffff && t < FLT_MAX)
+            atomicMin(&w_best[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)o);
+    };
 
     // 1. big spheres: plain sphereHit per real slot (there are only a few; pad slots of the last big group are skipped)
     Hit hb = { FLT_MAX, -1, 0x7fffffff };
@@ -345,18 +361,36 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);
                 }
                 mask <<= 16;                                         // slot0 at bit 31
-                Hit h = { FLT_MAX, -1, 0x7fffffff };
-                while (mask) {
-                    const int lz = __clz((int)mask);
-                    mask &= ~(0x80000000u >> lz);
-                    const int k = slot0 + lz;
-                    const float t = sphere_hit_exact(S.sph[sidx(k)], O, D, A, t_min, h.closest);
-                    const int o = S.orig[k];
-                    if (o != 0x7fffffff && t < FLT_MAX) accept(h, t, k, o);
+                // The spheres whose discriminant is positive (0..3 of the 16, most often 0 or 1) still need the exact
+                // sphereHit tail: IEEE sqrt + divide, 60 instructions.  Resolved in place, the wave would loop max-over-lanes
+                // times with a quarter of its lanes busy; instead every lane appends its candidates to a wave-wide LDS list
+                // and the list is resolved 64 candidates at a time, one per lane (order-free: the merge is an atomic min).
+                const uint32_t nc = (uint32_t)__popc(mask);
+                if (nc) {
+                    uint32_t at = atomicAdd(w_ccnt, nc);
+                    while (mask) {
+                        const int lz = __clz((int)mask);
+                        mask &= ~(0x80000000u >> lz);
+                        const uint32_t e = ((uint32_t)owner << 16) | (uint32_t)(slot0 + lz);
+                        if (at < (uint32_t)kCandCap) w_cand[at] = e; else resolve(e);      // list full (never seen on C2): in place
+                        at++;
+                    }
                 }
-                if (h.sid >= 0)
-                    atomicMin(&w_best[owner], ((unsigned long long)__float_as_uint(h.closest) << 32) | (unsigned long long)(uint32_t)h.orig);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);             // wave-uniform
+            if (n_c >= 64u) {
+                do {
+                    n_c -= 64u;
+                    resolve(w_cand[n_c + (uint32_t)lane]);
+                } while (n_c >= 64u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *w_ccnt = n_c;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         // carry the remainder to the front of the list
         carry = total - stop;
@@ -365,6 +399,12 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane < carry) w_pair[lane] = moved;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    {                                                                // the candidates left over: one partial batch
+        const uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);
+        if ((uint32_t)lane < n_c) resolve(w_cand[lane]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
