@@ -144,3 +144,53 @@ def test_mesh_fast_mode_within_tolerance(rt, O, stair):
     print("mesh fast: close", close.mean(), "rmse", rt.rmse(got, ref))
     assert close.mean() >= 0.90
     assert rt.rmse(got, ref) <= 0.05
+
+
+def _triangle_soup(rt, rng, n, n_mats=4):
+    tris = np.zeros(n, rt.triangle_dtype)
+    c = rng.uniform(-2, 2, (n, 1, 3)).astype(np.float32)
+    tris["v"] = c + rng.uniform(-0.7, 0.7, (n, 3, 3)).astype(np.float32)
+    tris["texCoords"] = rng.uniform(0, 1, (n, 6))
+    tris["meshID"] = rng.integers(0, n_mats, n)
+    mats = np.zeros(n_mats, rt.material_dtype)
+    mats["type"] = [rt.RT_DIFFUSE, rt.RT_METAL, rt.RT_GLASS, rt.RT_DIFFUSE][:n_mats]
+    mats["color"] = rng.uniform(0.2, 1, (n_mats, 3))
+    mats["param"] = [0.0, 0.1, 1.5, 0.0][:n_mats]
+    mats["texId"] = -1
+    return tris, mats
+
+
+@pytest.mark.parametrize("n,nppl", [(1, 1), (1, 5), (2, 1), (3, 2), (7, 5), (64, 8), (65, 3), (1000, 5), (1000, 16), (300, 20)])
+def test_triangle_soups_and_leaf_sizes_bit_exact(rt, O, n, nppl):
+    """Mesh shapes the staircase does not have: one triangle (the root's children are leaves), leaves of 1..20 slots (the
+    pair rounds of the leaf phase handle <= 16, above that the sequential loop runs), sentinel-padded last leaves, overlapping
+    random triangles with glass and metal.  NEE off: bit-exact image and equal ray / node-visit / triangle-test counts,
+    in the default traversal, the classic while-while and the tile kernel."""
+    rng = np.random.default_rng(4200 + 31 * n + nppl)
+    tris, mats = _triangle_soup(rt, rng, n)
+    hm = rt.HostMesh.build(tris, nppl)
+    nx, ny, ns = 72, 56, 3
+    cam = rt.make_camera((4.5, 2.5, 6.0), (0, 0, 0), (0, 1, 0), 40.0, nx / ny, 0.02, 8.0)
+    o = O.default_options(False)
+    o.nee = 0
+    ref, cnt = O.render(O.mesh_scene(hm, mats), cam, o, nx, ny, ns, 12, counters=True)
+    for variant in (0, 1 << 24, 1):
+        got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 12, nee=0, counters=1, variant=variant)
+        assert np.array_equal(_bits(got), _bits(ref)), (variant, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert (st.rays, st.node_visits, st.prim_tests) == (cnt.rays, cnt.node_visits, cnt.prim_tests), variant
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 300])
+def test_mesh_depth_limits(rt, O, stair, depth):
+    """maxDepth 0 (the loop of kernels.cu:402 never runs: black frame), 1, 2, and above 255 (`uint8_t bounce`,
+    helper_structs.h:58: clamped to 255 on both sides)."""
+    hm, mats = stair
+    nx, ny, ns = 48, 60, 2
+    cam = rt.staircase_camera(nx, ny)
+    o = O.default_options(False)
+    o.nee = 0
+    ref, _ = O.render(O.mesh_scene(hm, mats), cam, o, nx, ny, ns, min(depth, 255))
+    got, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, depth, nee=0)
+    assert np.array_equal(_bits(got), _bits(ref))
+    if depth == 0:
+        assert not got.any()
