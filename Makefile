@@ -22,12 +22,15 @@ $(OBJ):
 	@mkdir -p $(OBJ)
 
 # The two floating-point builds of each kernel TU: PARITY never contracts a*b+c into an FMA.
+# -fno-slp-vectorize -fno-vectorize (PARITY kernels): the vectorisers pair the un-fused mul/add of two boxes / two spheres into v_pk_mul_f32 /
+# v_pk_add_f32.  On gfx950 a packed mul/add issues in 4.56 cycles against 2 x 2.3 for the scalar pair (tools/valu_microbench.hip), so
+# it gains nothing, and the register shuffles (v_mov) that feed it cost 20 % of the box test.  FAST keeps it: v_pk_fma_f32 does pay.
 $(OBJ)/spheres_parity.o: $(CSRC)/rt_kernels_spheres.hip $(KERNEL_HDRS) | $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -fno-slp-vectorize -fno-vectorize -c $< -o $@
 $(OBJ)/spheres_fast.o: $(CSRC)/rt_kernels_spheres.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -c $< -o $@
 $(OBJ)/mesh_parity.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -fno-slp-vectorize -fno-vectorize -c $< -o $@
 $(OBJ)/mesh_fast.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -c $< -o $@
 $(OBJ)/probe_parity.o: $(CSRC)/rt_probe.hip $(KERNEL_HDRS) include/rt_probe.h | $(OBJ)

@@ -252,6 +252,7 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
 __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, f3 org, f3 inv, float closest, bool cull) {
     if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
     uint32_t need = 0;
+#pragma unroll 4                                                     // 4 box loads in flight: the loop is LDS-latency bound otherwise
     for (int g = 0; g < ng; g++) {
         const float4 lo = S.grp[2 * (g0 + g)], hi = S.grp[2 * (g0 + g) + 1];      // wave-uniform address: LDS broadcast
         const float x0 = (lo.x - org.x) * inv.x, x1 = (hi.x - org.x) * inv.x;
@@ -276,7 +277,10 @@ __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int n
 // The work a wave does is proportional to the pairs that exist, not to 64 x (union of groups): incoherent waves do not
 // pay for each other's groups, and a wave with few live rays uses all 64 lanes on them.  WAVE-LEVEL: all 64 lanes call it.
 __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, bool has_ray, bool cull,
-                                          uint32_t& groups_done) {
+                                          uint32_t& groups_done, unsigned long long* tm = nullptr) {
+    // tm (diagnostic instantiation only): cycles in [1] big spheres, [2] group boxes + pair list, [3] pair rounds, [4] candidates
+    unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
     float4* w_ray = reinterpret_cast<float4*>(W);                               // 64 x 2 float4
@@ -308,6 +312,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         }
     }
 
+    lap(1);
     w_ray[2 * lane] = make_float4(org.x, org.y, org.z, a);
     w_ray[2 * lane + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
     w_best[lane] = (hb.sid >= 0) ? (((unsigned long long)__float_as_uint(hb.closest) << 32) | (unsigned long long)(uint32_t)hb.orig) : ~0ull;
@@ -337,6 +342,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         __builtin_amdgcn_wave_barrier();
 
         const int stop = last_pass ? total : (total & ~63);          // full rounds only, except in the last pass
+        lap(2);
         for (int base = 0; base < stop; base += 64) {
             const int j = base + lane;
             if (j < stop) {
@@ -379,6 +385,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            lap(3);
             uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);             // wave-uniform
             if (n_c >= 64u) {
                 do {
@@ -391,6 +398,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             if (lane == 0) *w_ccnt = n_c;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            lap(4);
         }
         // carry the remainder to the front of the list
         carry = total - stop;
@@ -404,9 +412,11 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     }
     {                                                                // the candidates left over: one partial batch
         const uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);
+        lap(2);
         if ((uint32_t)lane < n_c) resolve(w_cand[lane]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        lap(4);
     }
     const unsigned long long key = w_best[lane];
     Hit out = { FLT_MAX, -1, 0x7fffffff };
@@ -548,15 +558,19 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done, int sparse_max = kSparseRays) {
+                                           uint32_t& groups_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr) {
+    // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
+    unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     // ---- hit(), kernels.cu:325-360: the ray is rebuilt from the path, which renormalises the direction
     const f3 dn = unit(L.dir);
     const float a = dot(dn, dn);
     Hit h = { FLT_MAX, -1, 0x7fffffff };
     const unsigned long long live = __ballot(has_ray);
+    lap(0);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
-        if (__popcll(live) <= sparse_max && coop_below == -1) h = scan_sparse(P, S, L.org, dn, a, live, cull);
-        else h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done);
+        if (__popcll(live) <= sparse_max && coop_below == -1) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
+        else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
     } else {
@@ -571,6 +585,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
     }
     bool done = false;
     if (has_ray) done = shade(P, S, L, dn, h);
+    lap(5);
     return done;
 }
 
@@ -862,6 +877,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
     const unsigned long long dbg_t0 = wdbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
+    unsigned long long dbg_tm[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // section cycles (see trace_rays), [7] refill, [8]/[9] main / boost steps
     float dbg_grab = 0.0f, dbg_p1 = 0.0f;                           // this lane's pixel: time it was grabbed, rays of phase 1
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
@@ -897,6 +913,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
 
     while (true) {
         // ---- refill idle lanes --------------------------------------------------------------------------------
+        const unsigned long long t_refill = (DBG && wdbg) ? __builtin_amdgcn_s_memtime() : 0ull;
         while (!exhausted) {
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
@@ -998,6 +1015,7 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             }
         }
         const unsigned long long live_now = __ballot(have_pixel);
+        if (DBG && wdbg) dbg_tm[7] += __builtin_amdgcn_s_memtime() - t_refill;
         if (live_now == 0ull) break;                                 // wave-uniform exit: idle lanes stay to help
         if (wdbg) {
             if (exhausted && dbg_tex == 0ull) dbg_tex = __builtin_amdgcn_s_memrealtime();
@@ -1031,7 +1049,8 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
             if (!LEGACY) {
                 if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             }
-            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max);
+            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr);
+            if (DBG && wdbg) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel);
         }
     }
@@ -1048,6 +1067,8 @@ __global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSp
         w[3] = dbg_iters; w[4] = dbg_coop_iters; w[5] = dbg_coop_rays;
         w[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
         w[7] = 1;
+        for (int k = 0; k < 8; k++) atomicAdd(wdbg + 65534ull * 8 + k, dbg_tm[k]);      // section cycles, summed over the waves
+        atomicAdd(wdbg + 65533ull * 8 + 0, dbg_tm[8]); atomicAdd(wdbg + 65533ull * 8 + 1, dbg_tm[9]);
     }
 }
 

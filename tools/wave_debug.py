@@ -2,6 +2,8 @@
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+sec, steps = a[65534].astype(np.float64), a[65533].astype(np.float64)
+a = a[:65533]
 a = a[a[:, 7] == 1]
 t0 = a[:, 0].min()
 start = (a[:, 0] - t0) / 1e5      # ms (100 MHz)
@@ -36,3 +38,10 @@ print("distinct CUs used:", len(uk), "waves per CU: min %d max %d" % (cnt.min(),
 for c in sorted(set(cnt)):
     sel = np.isin(key, uk[cnt == c])
     print("  CUs with %2d waves: %4d waves, median end %.1f ms, median exhausted %.1f" % (c, sel.sum(), np.median(end[sel]), np.nanmedian(tex[sel]) if np.isfinite(tex[sel]).any() else -1))
+
+if sec.sum() > 0:
+    names = ["ray set-up (unit dir)", "big spheres", "group boxes + pair list", "pair rounds (phase 1)", "candidates (exact tail)", "shade", "sparse scan", "refill / start pixel+sample"]
+    print("section cycles, all waves (share of the instrumented total):")
+    for n_, c in zip(names, sec):
+        print("  %-30s %5.1f %%" % (n_, 100 * c / sec.sum()))
+    print("  main steps %.3g, boost steps %.3g" % (steps[0], steps[1]))
