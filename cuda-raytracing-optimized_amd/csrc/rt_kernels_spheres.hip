@@ -252,7 +252,7 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
 __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, f3 org, f3 inv, float closest, bool cull) {
     if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
     uint32_t need = 0;
-#pragma unroll 4                                                     // 4 box loads in flight: the loop is LDS-latency bound otherwise
+#pragma unroll 4                                                     // 4 box loads in flight (8: slower): the loop is LDS-latency bound otherwise
     for (int g = 0; g < ng; g++) {
         const float4 lo = S.grp[2 * (g0 + g)], hi = S.grp[2 * (g0 + g) + 1];      // wave-uniform address: LDS broadcast
         const float x0 = (lo.x - org.x) * inv.x, x1 = (hi.x - org.x) * inv.x;
@@ -306,6 +306,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     Hit hb = { FLT_MAX, -1, 0x7fffffff };
     if (has_ray) {
         groups_done += (uint32_t)P.n_big_groups;
+#pragma unroll 4
         for (int k = 0; k < P.n_big; k++) {
             const float t = sphere_hit_exact(S.sph[sidx(k)], org, dn, a, t_min, hb.closest);   // wave-uniform address: LDS broadcast
             if (t < FLT_MAX) accept(hb, t, k, S.orig[k]);
