@@ -44,7 +44,7 @@ using namespace rtd;
 
 namespace {
 
-constexpr int kWavesPerWg = 4;              // 4 waves side by side: a 32 x 8 pixel tile per workgroup
+constexpr int kWavesPerWg = 8;              // 4 waves side by side: a 32 x 8 pixel tile per workgroup
 constexpr int kThreads = 64 * kWavesPerWg;
 constexpr int kPassGroups = 16;                                  // groups per pair-list pass: at most 64 x 16 pairs
 constexpr int kCandCap = 192;                                    // candidate list of the pair scan: 64 carried + up to 128 new per round
@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // irrelevant to the result because the seed is a function of the global pixel id only.
 
 template <bool LEGACY, bool DBG>
-__global__ void __launch_bounds__(kThreads, 3) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
+__global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
                                                                    int cull, int boost, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
@@ -1144,7 +1144,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 3;      // = the residency the kernel's VGPR budget (168) and LDS (~46 KB) allow
+    if (wg_per_cu == 0) wg_per_cu = 2;      // = the residency the kernel's VGPR budget (168) and LDS (~46 KB) allow
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + kThreads - 1) / kThreads;      // never more lanes than pixels
@@ -1161,7 +1161,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     }
     // chain waves: wave 0 of every 3rd workgroup; lanes above 10 rays per sample are boosted; chain lists = the first kChainClasses
     // (measured on C2: every third / 10 / 3 is the optimum of a flat basin)
-    const int chain_cfg = 3 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
+    const int chain_cfg = 2 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
     auto launch_queue = [&](const RtSphereParams& q, int classified) {
         const dim3 grid((unsigned)blocks), block(kThreads);
         if (legacy) hipLaunchKernelGGL((k_render_spheres_queue<true, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
