@@ -266,6 +266,19 @@ __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int n
     return need;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15
+// and row_bcast:31 carry the row totals across): six VALU instructions and no LDS round trip, where six __shfl_up steps are
+// six dependent ds_bpermute latencies.  WAVE-LEVEL: all 64 lanes must be active.
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 // ---- closest hit, PAIR-COMPACTED form (default) ---------------------------------------------------------------------
 // 1. Every live lane scans the BIG spheres (ground, unit spheres) for its own ray: a first `closest`.
 // 2. Every live lane finds the small-sphere groups its ray can still reach before that hit (a few of the ~31).
@@ -330,12 +343,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         const uint32_t need = has_ray ? group_needs(S, g0, ng, org, inv, hb.closest, cull) : 0u;
         // exclusive prefix sum of the pair counts over the wave
         const int cnt = __popc(need);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
+        const int incl = wave_inclusive_scan(cnt);
         const int total = carry + __builtin_amdgcn_readlane(incl, 63);
         int at = carry + incl - cnt;
         for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 8) | (g0 + __builtin_ctz(m)));
