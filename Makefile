@@ -28,7 +28,7 @@ $(OBJ):
 $(OBJ)/spheres_parity.o: $(CSRC)/rt_kernels_spheres.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -fno-slp-vectorize -fno-vectorize -c $< -o $@
 $(OBJ)/spheres_fast.o: $(CSRC)/rt_kernels_spheres.hip $(KERNEL_HDRS) | $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DRT_MODE_FAST -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -fno-vectorize -c $< -o $@
 $(OBJ)/mesh_parity.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_MODE_PARITY -ffp-contract=off -fno-slp-vectorize -fno-vectorize -c $< -o $@
 $(OBJ)/mesh_fast.o: $(CSRC)/rt_kernels_mesh.hip $(KERNEL_HDRS) | $(OBJ)

@@ -315,21 +315,55 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             atomicMin(&w_best[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)o);
     };
 
-    // 1. big spheres: plain sphereHit per real slot (there are only a few; pad slots of the last big group are skipped)
-    Hit hb = { FLT_MAX, -1, 0x7fffffff };
-    if (has_ray) {
-        groups_done += (uint32_t)P.n_big_groups;
-#pragma unroll 4
-        for (int k = 0; k < P.n_big; k++) {
-            const float t = sphere_hit_exact(S.sph[sidx(k)], org, dn, a, t_min, hb.closest);   // wave-uniform address: LDS broadcast
-            if (t < FLT_MAX) accept(hb, t, k, S.orig[k]);
-        }
-    }
-
-    lap(1);
     w_ray[2 * lane] = make_float4(org.x, org.y, org.z, a);
     w_ray[2 * lane + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
-    w_best[lane] = (hb.sid >= 0) ? (((unsigned long long)__float_as_uint(hb.closest) << 32) | (unsigned long long)(uint32_t)hb.orig) : ~0ull;
+    w_best[lane] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // publishes the ray table and the zeroed candidate counter
+    __builtin_amdgcn_wave_barrier();
+
+    // 1. big spheres (ground, unit spheres; there are only a few): every lane runs phase 1 for its own ray.  The exact
+    //    sphereHit tail (IEEE sqrt + divide, taken by an uneven half of the lanes) goes through the candidate list like any
+    //    other; what the group culling below needs NOW is only an upper bound of the closest big-sphere hit.  `bound` is
+    //    that: the roots from v_sqrt_f32 / v_rcp_f32 (1 ulp each) pushed up by 6x their worst-case error, and a root is only
+    //    trusted to lie above t_min if it does so by that margin - so bound >= the exact closest hit of the reference
+    //    (near root accepted: closest <= t1 <= bound; near root at or below t_min: the far root bounds whatever is accepted).
+    float bound = FLT_MAX;
+    if (has_ray) {
+        groups_done += (uint32_t)P.n_big_groups;
+        const float ra = __builtin_amdgcn_rcpf(a);
+        for (int k0 = 0; k0 < P.n_big; k0 += 32) {
+            uint32_t bm = 0;
+            const int kn = min(32, P.n_big - k0);
+#pragma unroll 4
+            for (int k = 0; k < kn; k++) {
+                const float4 sph = S.sph[sidx(k0 + k)];              // wave-uniform address: LDS broadcast
+                const float ocx = org.x - sph.x, ocy = org.y - sph.y, ocz = org.z - sph.z;
+                const float b = ocx * dn.x + ocy * dn.y + ocz * dn.z;
+                const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
+                const float nd = a * c - b * b;                      // == -(b*b - a*c) bit for bit
+                const bool cand = nd < 0.0f;
+                const float sq = __builtin_amdgcn_sqrtf(fmaxf(-nd, 0.0f));
+                const float err = (fabsf(b) + sq) * ra * 2.0e-6f;
+                const float t1 = (-b - sq) * ra, t2 = (-b + sq) * ra;
+                const float lo = t_min + err;
+                const float tb = t1 > lo ? t1 + err : (t2 > lo ? t2 + err : FLT_MAX);
+                if (cand) bound = fminf(bound, tb);
+                bm |= (cand ? 1u : 0u) << k;
+            }
+            const uint32_t nc = (uint32_t)__popc(bm);
+            if (nc) {
+                uint32_t at = atomicAdd(w_ccnt, nc);
+                while (bm) {
+                    const int k = __builtin_ctz(bm);
+                    bm &= bm - 1u;
+                    const uint32_t e = ((uint32_t)lane << 16) | (uint32_t)(k0 + k);
+                    if (at < (uint32_t)kCandCap) w_cand[at] = e; else resolve(e);
+                    at++;
+                }
+            }
+        }
+    }
+    lap(1);
     // v_rcp_f32 (1 ulp) is enough here: the slab test is conservative by 1e-5 relative
     const f3 inv = F3(__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z));
 
@@ -340,7 +374,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
         const int ng = min(kPassGroups, P.n_groups - g0);
         const bool last_pass = g0 + kPassGroups >= P.n_groups;
-        const uint32_t need = has_ray ? group_needs(S, g0, ng, org, inv, hb.closest, cull) : 0u;
+        const uint32_t need = has_ray ? group_needs(S, g0, ng, org, inv, bound, cull) : 0u;
         // exclusive prefix sum of the pair counts over the wave
         const int cnt = __popc(need);
         const int incl = wave_inclusive_scan(cnt);
@@ -419,10 +453,14 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    {                                                                // the candidates left over: one partial batch
-        const uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);
+    {                                                                // the candidates left over
+        uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);
         lap(2);
-        if ((uint32_t)lane < n_c) resolve(w_cand[lane]);
+        while (n_c > 0u) {                                           // (more than 64 only if no pair round ran after the big spheres)
+            const uint32_t take = min(n_c, 64u);
+            n_c -= take;
+            if ((uint32_t)lane < take) resolve(w_cand[n_c + (uint32_t)lane]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         lap(4);

@@ -168,7 +168,7 @@ def _random_scene(rt, rng, n, big=1, dup=0):
     return sp, mt
 
 
-@pytest.mark.parametrize("n,big,dup", [(1, 1, 0), (2, 0, 0), (17, 1, 3), (33, 0, 5), (64, 2, 0), (65, 1, 8), (300, 3, 20), (1500, 1, 0)])
+@pytest.mark.parametrize("n,big,dup", [(1, 1, 0), (2, 0, 0), (17, 1, 3), (33, 0, 5), (64, 2, 0), (65, 1, 8), (300, 3, 20), (1500, 1, 0), (500, 40, 0), (40, 40, 0)])
 def test_arbitrary_sphere_scenes_bit_exact(rt, O, n, big, dup):
     """Scene shapes the benchmark does not have: 1 sphere, no big spheres, only a few small ones, group counts
     that are not multiples of 4, > 1024 spheres, and EXACT duplicate spheres with different materials (an exact
@@ -193,6 +193,26 @@ def test_camera_inside_scene_and_odd_image_sizes(rt, O):
         ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, 4, 12)
         got, _ = _render_gpu(rt, sp, mt, cam, nx, ny, 4, 12)
         assert np.array_equal(_bits(got), _bits(ref)), (nx, ny)
+
+
+def test_camera_inside_big_spheres_and_small_t_min(rt, O):
+    """The big spheres (always-tested class) reach the group culling only through a conservative bound of their closest hit
+    and are resolved exactly through the candidate list: origins INSIDE big spheres (near root negative, far root accepted),
+    grazing rays, more than 32 big spheres (two bound chunks), and t_min values down to 0 (no self-hit rejection margin)."""
+    rng = np.random.default_rng(99)
+    sp, mt = _random_scene(rt, rng, 260, 1, 0)
+    sp["radius"][1:36] = rng.uniform(2.0, 4.0, 35)          # 36 big spheres around and over the camera
+    sp["center"][1] = (0.2, 0.3, 0.1); sp["radius"][1] = 3.0
+    mt["type"][1] = rt.RT_GLASS; mt["param"][1] = 1.5
+    nx, ny, ns = 64, 48, 4
+    cam = rt.make_camera((0.3, 0.4, 0.2), (2, 0.2, 1), (0, 1, 0), 70.0, nx / ny, 0.0, 1.0)
+    for t_min in (0.001, 1e-5, 0.0, 0.25):
+        o = O.default_options(True)
+        o.t_min = t_min
+        ref, cnt = O.render(O.sphere_scene(sp, mt), cam, o, nx, ny, ns, 12, counters=True)
+        got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 12, counters=1, t_min=t_min)
+        assert np.array_equal(_bits(got), _bits(ref)), (t_min, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert st.rays == cnt.rays, t_min
 
 
 def test_in_process_multi_device_path(rt, O):
