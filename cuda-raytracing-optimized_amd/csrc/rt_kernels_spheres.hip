@@ -246,11 +246,14 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
 // Which small-sphere groups can still give this ray a closer hit?  Slab test of the ray against the group's inflated
 // AABB; bit g = "the ray enters the box at a distance not beyond its current closest hit".  Conservative by
 // construction: the box is inflated on the host by far more than the rounding error of this test, the entry distance is
-// shrunk by 1e-5 relative + 1e-4 absolute before it is compared, and any NaN (0 * inf on a slab plane) compares false,
-// i.e. keeps the group.  A skipped group could only have produced hits with t > closest, which the reference rejects.
+// shrunk by 1e-5 relative + 1e-4 absolute before it is compared, and a NaN (0 * inf on a slab plane) is dropped by
+// min/max or compares false, i.e. keeps the group.  A skipped group could only have produced hits with t > closest, which the reference rejects.
 // Handles up to 32 groups per call (groups g0 .. g0+ng-1).
 __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, f3 org, f3 inv, float closest, bool cull) {
     if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
+    // the entry distance shrunk by 1e-5 relative + 1e-4 absolute must not exceed `closest`:  t_in * 0.99999 - 1e-4 > closest
+    // is implied by t_in > cb with cb = (closest + 1e-4) * 1.00002 >= (closest + 1e-4) / 0.99999 (hoisted out of the loop)
+    const float cb = (closest + 1.0e-4f) * 1.00002f;
     uint32_t need = 0;
 #pragma unroll 4                                                     // 4 box loads in flight (8: slower): the loop is LDS-latency bound otherwise
     for (int g = 0; g < ng; g++) {
@@ -260,7 +263,8 @@ __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int n
         const float z0 = (lo.z - org.z) * inv.z, z1 = (hi.z - org.z) * inv.z;
         const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
         const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const bool skip = (t_in > t_out) || (t_out < 0.0f) || (t_in * 0.99999f - 1.0e-4f > closest);
+        // (t_in > t_out) || (t_out < 0) || (t_in > cb), cb >= 0, in four instructions
+        const bool skip = fmaxf(t_in, 0.0f) > fminf(t_out, cb);
         need |= (skip ? 0u : 1u) << g;
     }
     return need;
