@@ -326,15 +326,14 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
     const float eps = P.t_min;
     // leaf phase of TRAV 0: per-wave LDS scratch and this lane's fixed role in a pair round (ray j / nppl, triangle j % nppl)
-    __shared__ uint32_t s_owner[kThreads], s_sent[kThreads];
+    __shared__ uint32_t s_owner[kThreads];
     __shared__ unsigned long long s_best[kThreads];
     __shared__ float2 s_uv[kThreads];
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* w_owner = s_owner + (threadIdx.x & ~63u);
-    uint32_t* w_sent = s_sent + (threadIdx.x & ~63u);
     unsigned long long* w_best = s_best + (threadIdx.x & ~63u);
     float2* w_uv = s_uv + (threadIdx.x & ~63u);
-    const int pair_per = (TRAV == 0 && P.nppl >= 1u && P.nppl <= 16u) ? (int)(64u / P.nppl) : 0;     // rays per pair round
+    const int pair_per = (TRAV == 0 && P.leaf_sentinels_trailing && P.nppl >= 1u && P.nppl <= 16u) ? (int)(64u / P.nppl) : 0;     // rays per pair round
     const uint32_t pair_r = pair_per ? lane / P.nppl : 0u;
     const uint32_t pair_k = pair_per ? lane - pair_r * P.nppl : 0u;
     const bool pair_ok = pair_per && (int)pair_r < pair_per;
@@ -569,19 +568,14 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         const bool at_leaf = act && !at_node;
                         const unsigned long long leaf_m = __ballot(at_leaf);
                         const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(leaf_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)leaf_m, 0u));
-                        if (at_leaf) w_owner[my_rank] = lane;
+                        if (at_leaf) { w_owner[my_rank] = lane; w_best[lane] = ~0ull; }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t packed = (uint32_t)J.idx | (J.shadow ? 0x80000000u : 0u);
-                        unsigned long long my_best = ~0ull;              // owner side: result of my leaf
-                        float my_u = 0.0f, my_v = 0.0f;
                         for (int base = 0; base < n_leaf; base += pair_per) {
                             const int r = base + (int)pair_r;
                             const bool pv = pair_ok && r < n_leaf;
                             const uint32_t owner = pv ? w_owner[r] : lane;
-                            if (pv) { w_sent[owner] = 0xFFFFFFFFu; w_best[owner] = ~0ull; }      // same value from every pair lane of the owner
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
                             const int src = (int)(owner << 2);
                             const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.x)));
                             const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.y)));
@@ -593,22 +587,14 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                             const uint32_t o_packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)packed);
                             const bool o_shadow = (o_packed & 0x80000000u) != 0u;
                             const uint32_t slot = ((o_packed & 0x7FFFFFFFu) - P.first_leaf) * P.nppl + pair_k;
-                            float4 ta = make_float4(0, 0, 0, 0), tb = ta;
-                            float tcx = 0.0f;
-                            bool sent = false;
-                            if (pv) {
-                                const float4* pt = reinterpret_cast<const float4*>(P.tris + slot);
-                                ta = pt[0]; tb = pt[1]; tcx = pt[2].x;
-                                sent = isinf(ta.x);                      // kernels.cu:202 sentinel
-                                if (sent) atomicMin(&w_sent[owner], pair_k);
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
                             bool reached = false, hit = false;
                             float u = 0.0f, v = 0.0f;
                             unsigned long long key = ~0ull;
                             if (pv) {
-                                reached = pair_k < w_sent[owner];        // the loop breaks at the first sentinel
+                                const float4* pt = reinterpret_cast<const float4*>(P.tris + slot);
+                                const float4 ta = pt[0], tb = pt[1];
+                                const float tcx = pt[2].x;
+                                reached = !isinf(ta.x);                  // kernels.cu:202 sentinel; sentinels are trailing (checked on the host)
                                 if (reached) {
                                     Ray pr;
                                     pr.o = F3(ox, oy, oz); pr.d = F3(dx, dy, dz); pr.inv = F3(0, 0, 0);
@@ -629,15 +615,15 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                                 if (reached && (!o_shadow || best == ~0ull || (unsigned long long)pair_k <= best)) st.tests++;
                                 if (hit && key == best) w_uv[owner] = make_float2(u, v);
                             }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            if (at_leaf && (int)my_rank >= base && (int)my_rank < base + pair_per) {
-                                my_best = w_best[lane];
-                                const float2 uv = w_uv[lane];
-                                my_u = uv.x; my_v = uv.y;
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        unsigned long long my_best = ~0ull;              // owner side: result of my leaf
+                        float my_u = 0.0f, my_v = 0.0f;
+                        if (at_leaf) {
+                            my_best = w_best[lane];
+                            const float2 uv = w_uv[lane];
+                            my_u = uv.x; my_v = uv.y;
                         }
                         if (at_leaf) {
                             if (my_best != ~0ull && J.shadow) {          // any-hit: hitBvh returns 0.0f (kernels.cu:205)

@@ -67,6 +67,7 @@ struct RtMeshParams {
     const float4* bvh4;         // heap-indexed nodes viewed as float4 texels: child pair of node i at texels 3i..3i+2
     uint32_t first_leaf;
     uint32_t nppl;
+    int32_t leaf_sentinels_trailing;   // host-checked: no real triangle behind a sentinel in any leaf (pair rounds allowed)
     rt_bbox bounds;
     const rt_material* materials;
     const float* const* tex_data;

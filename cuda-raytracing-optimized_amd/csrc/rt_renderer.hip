@@ -94,6 +94,7 @@ struct RenderContext {
     std::vector<float4> h_bvh;          // numBvhNodes * 24 B viewed as float4 (padded)
     int num_bvh_nodes = 0;
     int nppl = 0;
+    int leaf_sentinels_trailing = 1;
     rt_bbox bounds;
     std::vector<rt_material> h_materials;
     std::vector<std::vector<float>> h_tex;
@@ -380,6 +381,18 @@ void initRenderer(const rt_kernel_scene sc, const rt_camera cam, rt_vec3** fb, i
     c.h_bvh.assign((nfloats + 3) / 4 + 1, make_float4(0, 0, 0, 0));
     memcpy(c.h_bvh.data(), sc.m->bvh, nfloats * sizeof(float));
     c.nppl = sc.numPrimitivesPerLeaf;                                                          // kernels.cu:648
+    // The leaf loop of kernels.cu:196-214 stops at the first sentinel (inf) triangle of a leaf.  The pair rounds of the mesh
+    // kernel test a leaf's triangles in parallel and rely on sentinels being TRAILING (true for every builder that pads
+    // leaves at the end); a leaf with a real triangle behind a sentinel sends the kernel to its sequential leaf loop.
+    c.leaf_sentinels_trailing = 1;
+    for (uint32_t leaf = 0; leaf < first_leaf && c.leaf_sentinels_trailing; leaf++) {
+        bool seen = false;
+        for (int k = 0; k < c.nppl; k++) {
+            const bool sent = std::isinf(c.h_tris[(size_t)leaf * c.nppl + k].v[0].e[0]);
+            if (seen && !sent) c.leaf_sentinels_trailing = 0;
+            seen = seen || sent;
+        }
+    }
     c.bounds = sc.m->bounds;
     c.h_materials.assign(sc.materials, sc.materials + sc.numMaterials);                        // kernels.cu:617-618
     c.h_tex.clear(); c.h_tex_w.clear(); c.h_tex_h.clear();
@@ -500,6 +513,7 @@ void runRenderer(int ns, int tx, int ty) {
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
             p.tris = d.d_tris; p.bvh4 = d.d_bvh;
             p.first_leaf = (uint32_t)c.num_bvh_nodes / 2; p.nppl = (uint32_t)c.nppl; p.bounds = c.bounds;
+            p.leaf_sentinels_trailing = c.leaf_sentinels_trailing;
             p.materials = d.d_materials;
             p.tex_data = d.d_tex_data; p.tex_width = d.d_tex_width; p.tex_height = d.d_tex_height;
             p.fb = d.d_fb; p.part = part;

@@ -194,3 +194,28 @@ def test_mesh_depth_limits(rt, O, stair, depth):
     assert np.array_equal(_bits(got), _bits(ref))
     if depth == 0:
         assert not got.any()
+
+
+def test_sentinel_in_the_middle_of_a_leaf(rt, O):
+    """kernels.cu:202 stops a leaf at its FIRST sentinel triangle.  Builders pad leaves at the end, and the pair rounds of
+    the mesh kernel rely on that; initRenderer checks it and a mesh with a real triangle BEHIND a sentinel takes the
+    sequential leaf loop instead.  Same bits and counts as the oracle (which follows the reference literally)."""
+    rng = np.random.default_rng(515)
+    tris, mats = _triangle_soup(rt, rng, 200)
+    hm = rt.HostMesh.build(tris, 5)
+    t = hm.tris
+    poked = 0
+    for leaf in range(0, len(t) // 5, 3):
+        if not np.isinf(t["v"][leaf * 5 + 2, 0, 0]):        # slots 0..2 real: hide slot 1, slot 2 becomes unreachable
+            t["v"][leaf * 5 + 1, 0, 0] = np.inf
+            poked += 1
+    assert poked > 3
+    nx, ny, ns = 72, 56, 3
+    cam = rt.make_camera((4.5, 2.5, 6.0), (0, 0, 0), (0, 1, 0), 40.0, nx / ny, 0.02, 8.0)
+    o = O.default_options(False)
+    o.nee = 0
+    ref, cnt = O.render(O.mesh_scene(hm, mats), cam, o, nx, ny, ns, 12, counters=True)
+    for variant in (0, 1 << 24):
+        got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 12, nee=0, counters=1, variant=variant)
+        assert np.array_equal(_bits(got), _bits(ref)), variant
+        assert (st.rays, st.node_visits, st.prim_tests) == (cnt.rays, cnt.node_visits, cnt.prim_tests), variant
