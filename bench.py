@@ -59,7 +59,7 @@ def cpu_baseline(rt, nx, ny):
     restatement of it when the shim is absent, timed on a bounded sample of the SAME workload:
     the full 1200x800 frame, first CPU_SPP samples of every pixel stream."""
     from oracle import oracle as O
-    cpu_spp = int(os.environ.get("RT_BENCH_CPU_SPP", "4"))
+    cpu_spp = int(os.environ.get("RT_BENCH_CPU_SPP", "8"))       # ~13 s of single-threaded CPU work
     sp, mt, cam = rt.scene_random_spheres(nx, ny)
     opt = O.default_options(True)
     t0 = time.perf_counter()
