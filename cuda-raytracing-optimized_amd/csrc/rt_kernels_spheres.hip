@@ -44,7 +44,7 @@ using namespace rtd;
 
 namespace {
 
-constexpr int kWavesPerWg = 8;              // 4 waves side by side: a 32 x 8 pixel tile per workgroup
+constexpr int kWavesPerWg = 8;              // 8 waves share one LDS copy of the scene (tile kernel: 8 tiles side by side, 64 x 8 pixels)
 constexpr int kThreads = 64 * kWavesPerWg;
 constexpr int kPassGroups = 16;                                  // groups per pair-list pass: at most 64 x 16 pairs
 constexpr int kCandCap = 192;                                    // candidate list of the pair scan: 64 carried + up to 128 new per round
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     // Chain waves.  A lane that is not boosted advances ONE ray per wave iteration, and an iteration takes 3-4 us for <= 4
     // live lanes (sparse form) but 15-25 us for 64: a pixel handed out at time T ends near T + rays x iteration time, and
     // the longest pixels (3700 rays: 50 bounces inside glass, sample after sample) would end the frame at 60 ms.
-    // So one wave in twelve (role 0: wave 0 of every third workgroup) serves the chain lists from their own counter
+    // So one wave in sixteen (role 0: wave 0 of every second workgroup) serves the chain lists from their own counter
     // (P.queue[1]), longest first, and holds at most kSparseRays pixels: it always runs the sparse form, at raised
     // priority, and the longest chain is over after 15 ms.  When the chain lists are empty the wave becomes a normal wave
     // (role 2: general queue, all 64 lanes), but keeps the cap for as long as it still holds a chain pixel.
@@ -1194,7 +1194,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 2;      // = the residency the kernel's VGPR budget (168) and LDS (~46 KB) allow
+    if (wg_per_cu == 0) wg_per_cu = 2;      // = the residency the kernel's launch bound (4 waves/SIMD, 128 VGPRs) and LDS (~70 KB per workgroup) allow
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + kThreads - 1) / kThreads;      // never more lanes than pixels
@@ -1209,8 +1209,8 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
-    // chain waves: wave 0 of every 3rd workgroup; lanes above 10 rays per sample are boosted; chain lists = the first kChainClasses
-    // (measured on C2: every third / 10 / 3 is the optimum of a flat basin)
+    // chain waves: wave 0 of every 2nd workgroup (256 waves); lanes above 10 rays per sample are boosted; chain lists = the
+    // first kChainClasses (measured on C2: 256 waves / 10 / 3 is the optimum of a flat basin)
     const int chain_cfg = 2 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
     auto launch_queue = [&](const RtSphereParams& q, int classified) {
         const dim3 grid((unsigned)blocks), block(kThreads);
