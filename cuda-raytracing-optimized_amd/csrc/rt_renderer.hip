@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -268,24 +269,37 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
             hi[a] = std::max(hi[a], (double)spheres[k].center.e[a]);
         }
     }
-    auto morton = [&](int k) {
-        uint32_t code = 0, q[3];
-        for (int a = 0; a < 3; a++) {
-            const double ext = hi[a] - lo[a];
-            q[a] = ext > 0 ? (uint32_t)std::min(1023.0, (spheres[k].center.e[a] - lo[a]) / ext * 1024.0) : 0u;
+    // Groups of 16: recursive median split of the small spheres along the axis of largest centre extent, the left part
+    // rounded to a multiple of 16, until a part fits one group.  Compact parts = small boxes = few (ray, group) pairs; a
+    // 3D Morton sort (the first version) makes strips and L-shapes when the spheres lie on a plane.  ceil(n / 16) groups.
+    std::vector<int> ordered;
+    std::function<void(std::vector<int>&, size_t, size_t)> split = [&](std::vector<int>& v, size_t b0, size_t e0) {
+        const size_t cnt = e0 - b0;
+        if (cnt <= 16) {
+            for (size_t q = b0; q < e0; q++) ordered.push_back(v[q]);
+            while (ordered.size() % 16) ordered.push_back(-1);     // pad this group
+            return;
         }
-        for (int b = 9; b >= 0; b--)
-            for (int a = 0; a < 3; a++) code = (code << 1) | ((q[a] >> b) & 1u);
-        return code;
+        double l3[3] = { 1e300, 1e300, 1e300 }, h3[3] = { -1e300, -1e300, -1e300 };
+        for (size_t q = b0; q < e0; q++)
+            for (int a = 0; a < 3; a++) {
+                l3[a] = std::min(l3[a], (double)spheres[v[q]].center.e[a]);
+                h3[a] = std::max(h3[a], (double)spheres[v[q]].center.e[a]);
+            }
+        int axis = 0;
+        for (int a = 1; a < 3; a++) if (h3[a] - l3[a] > h3[axis] - l3[axis]) axis = a;
+        std::stable_sort(v.begin() + b0, v.begin() + e0, [&](int x, int y) { return spheres[x].center.e[axis] < spheres[y].center.e[axis]; });
+        const size_t groups = (cnt + 15) / 16;
+        const size_t left = std::min(cnt - 1, (groups / 2) * 16);    // a multiple of 16: only the last group of the scene is padded
+        split(v, b0, b0 + left);
+        split(v, b0 + left, e0);
     };
-    std::vector<std::pair<uint32_t, int>> keyed;
-    for (int k : small) keyed.emplace_back(morton(k), k);
-    std::sort(keyed.begin(), keyed.end());
     std::vector<int> slots;                                     // slot -> caller index, -1 = pad
     for (int k : big) slots.push_back(k);                       // big spheres first: groups [0, n_big_groups)
     while (slots.size() % 16) slots.push_back(-1);
     const int n_big_groups = (int)slots.size() / 16;
-    for (auto& kv : keyed) slots.push_back(kv.second);
+    if (!small.empty()) split(small, 0, small.size());
+    for (int k : ordered) slots.push_back(k);
     while (slots.size() % 64) slots.push_back(-1);
 
     double extent = 1.0;
