@@ -83,7 +83,7 @@ __device__ __forceinline__ void accept(Hit& h, float t, int slot, int orig) {
 }
 
 // LDS image of the scene, staged once per workgroup (README.md:93-103 used __constant__).
-__device__ __forceinline__ int sidx(int slot) { return slot + (slot >> 4); }
+__device__ __forceinline__ int sidx(int slot) { return slot + (slot >> kSphereGroupShift); }
 
 struct SceneLds {
     const float4* sph;      // (cx, cy, cz, r*r) of slot k at index sidx(k) = k + k/16: 17 float4 per group of 16, so that
@@ -162,11 +162,11 @@ __device__ __forceinline__ void start_pixel(const RtSphereParams& P, Lane& L, in
 // Phase 1: 16 VALU ops per sphere in exactly the reference's rounding order + one v_alignbit that shifts the sign of
 // -(discriminant) into a mask.  Phase 2: the literal sphereHit tail for the set bits only.
 __device__ __forceinline__ void scan_group_broadcast(const RtSphereParams& P, const SceneLds& S, int g, f3 org, f3 dn, float a, Hit& h) {
-    const int base = g << 4;
+    const int base = g << kSphereGroupShift;
     const float4* sp = S.sph + sidx(base);
     uint32_t mask = 0;
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
+    for (int kk = 0; kk < kSphereGroup; kk++) {
         const float4 sph = sp[kk];                                   // wave-uniform address: LDS broadcast
         const float ocx = org.x - sph.x;
         const float ocy = org.y - sph.y;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void scan_group_broadcast(const RtSphereParams& P, co
         const float nd = a * c - b * b;                              // == -(b*b - a*c) bit for bit
         mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);   // mask = mask<<1 | sign(nd)
     }
-    mask <<= 16;                                                     // slot `base` at bit 31
+    mask <<= (32 - kSphereGroup);                                    // slot `base` at bit 31
     while (mask) {                                                   // candidates
         const int lz = __clz((int)mask);
         mask &= ~(0x80000000u >> lz);
@@ -395,7 +395,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             if (j < stop) {
                 const unsigned pr = w_pair[j];
                 const int owner = (int)(pr >> 8);
-                const int slot0 = (int)(pr & 0xFFu) << 4;
+                const int slot0 = (int)(pr & 0xFFu) << kSphereGroupShift;
                 const int sbase = sidx(slot0);
                 const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
@@ -403,7 +403,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 groups_done++;
                 uint32_t mask = 0;
 #pragma unroll 8
-                for (int kk = 0; kk < 16; kk++) {                    // 8 sphere loads in flight at a time keeps the kernel inside its VGPR budget
+                for (int kk = 0; kk < kSphereGroup; kk++) {          // 8 sphere loads in flight at a time keeps the kernel inside its VGPR budget
                     const float4 sph = S.sph[sbase + kk];
                     const float ocx = O.x - sph.x;
                     const float ocy = O.y - sph.y;
@@ -413,7 +413,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                     const float nd = A * c - b * b;                  // == -(b*b - a*c) bit for bit
                     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);
                 }
-                mask <<= 16;                                         // slot0 at bit 31
+                mask <<= (32 - kSphereGroup);                        // slot0 at bit 31
                 // The spheres whose discriminant is positive (0..3 of the 16, most often 0 or 1) still need the exact
                 // sphereHit tail: IEEE sqrt + divide, 60 instructions.  Resolved in place, the wave would loop max-over-lanes
                 // times with a quarter of its lanes busy; instead every lane appends its candidates to a wave-wide LDS list
@@ -519,8 +519,8 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.z), q)));
         const float A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), q));
         // (a) big spheres: one slot per lane
-        for (int s0 = 0; s0 < (P.n_big_groups << 4); s0 += 64)
-            if (s0 + lane < (P.n_big_groups << 4)) sparse_test_slot(P, S, s0 + lane, O, D, A, &w_best[q]);
+        for (int s0 = 0; s0 < (P.n_big_groups << kSphereGroupShift); s0 += 64)
+            if (s0 + lane < (P.n_big_groups << kSphereGroupShift)) sparse_test_slot(P, S, s0 + lane, O, D, A, &w_best[q]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const float closest = __uint_as_float((uint32_t)(w_best[q] >> 32));      // FLT_MAX-or-larger bit pattern if none: keeps everything
@@ -546,14 +546,14 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
             while (gm) {
                 int gsel = -1;                                       // this lane's group: the (lane>>4)-th of the next 4 set bits
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
+                for (int w = 0; w < 64 / kSphereGroup; w++) {
                     if (gm) {
                         const int gb = __builtin_ctzll(gm);
                         gm &= gm - 1;
-                        if ((lane >> 4) == w) gsel = g0 + gb;
+                        if ((lane >> kSphereGroupShift) == w) gsel = g0 + gb;
                     }
                 }
-                if (gsel >= 0) sparse_test_slot(P, S, (gsel << 4) + (lane & 15), O, D, A, &w_best[q]);
+                if (gsel >= 0) sparse_test_slot(P, S, (gsel << kSphereGroupShift) + (lane & (kSphereGroup - 1)), O, D, A, &w_best[q]);
             }
         }
     }
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
-        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 16ull);     // lane-parallel phase-1 tests executed
+        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * (unsigned long long)kSphereGroup);     // lane-parallel phase-1 tests executed
     }
 }
 
@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
-        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 16ull);     // lane-parallel phase-1 tests executed
+        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * (unsigned long long)kSphereGroup);     // lane-parallel phase-1 tests executed
     }
     if (wdbg) atomicMax(wdbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
     if (wdbg && (threadIdx.x & 63) == 0) {
@@ -1141,7 +1141,7 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 
 static size_t lds_bytes(int n_padded, int n) {
     // spheres + group bounds + material colour + type + original index per slot, + fb staging of the tile kernel
-    return (size_t)(n_padded + n_padded / 16) * 16 + (size_t)(n_padded / 16) * 32 + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
+    return (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 32 + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
            (size_t)((n + 3) & ~3) * 4 + (size_t)kThreads * 3 * 4 + (size_t)kWavesPerWg * kWaveScratch;
 }
 

@@ -87,7 +87,7 @@ struct RenderContext {
     std::vector<float4> h_spheres;      // padded
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
-    std::vector<float4> h_groups;       // two float4 per group of 16 slots: inflated AABB lo / hi
+    std::vector<float4> h_groups;       // two float4 per group of kSphereGroup slots: inflated AABB lo / hi
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
     int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0, n_big = 0;
@@ -242,11 +242,11 @@ void common_init(const rt_camera& cam, rt_vec3** fb, int nx, int ny, int maxDept
 }
 
 
-// Device layout of a sphere scene.  The spheres are re-ordered into SLOTS, 16 slots per group:
+// Device layout of a sphere scene.  The spheres are re-ordered into SLOTS, kSphereGroup (G) slots per group:
 //   * "big" spheres (radius > 4 x the median radius: the ground and the three unit spheres of the benchmark scene)
 //     come first; their groups are always scanned, by every lane, and give each ray a first `closest`;
 //   * "small" spheres are sorted along a 3D Morton curve so that consecutive slots are neighbours in space; each
-//     group of 16 gets an axis-aligned bounding box, inflated well beyond fp32 rounding (1 % + 1e-4 of the scene
+//     group of G gets an axis-aligned bounding box, inflated well beyond fp32 rounding (1 % + 1e-4 of the scene
 //     extent), which the kernel uses to skip the group for rays that cannot reach it before their current hit;
 //   * pad slots fill the last group of each class and the tail up to a multiple of 64 slots; they carry
 //     orig = INT_MAX and are never accepted.
@@ -269,15 +269,16 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
             hi[a] = std::max(hi[a], (double)spheres[k].center.e[a]);
         }
     }
-    // Groups of 16: recursive median split of the small spheres along the axis of largest centre extent, the left part
-    // rounded to a multiple of 16, until a part fits one group.  Compact parts = small boxes = few (ray, group) pairs; a
-    // 3D Morton sort (the first version) makes strips and L-shapes when the spheres lie on a plane.  ceil(n / 16) groups.
+    // Groups of G = kSphereGroup: recursive median split of the small spheres along the axis of largest centre extent, the left part
+    // rounded to a multiple of G, until a part fits one group.  Compact parts = small boxes = few (ray, group) pairs; a
+    // 3D Morton sort (the first version) makes strips and L-shapes when the spheres lie on a plane.  ceil(n / G) groups.
+    constexpr size_t G = (size_t)kSphereGroup;
     std::vector<int> ordered;
     std::function<void(std::vector<int>&, size_t, size_t)> split = [&](std::vector<int>& v, size_t b0, size_t e0) {
         const size_t cnt = e0 - b0;
-        if (cnt <= 16) {
+        if (cnt <= (size_t)G) {
             for (size_t q = b0; q < e0; q++) ordered.push_back(v[q]);
-            while (ordered.size() % 16) ordered.push_back(-1);     // pad this group
+            while (ordered.size() % G) ordered.push_back(-1);      // pad this group
             return;
         }
         double l3[3] = { 1e300, 1e300, 1e300 }, h3[3] = { -1e300, -1e300, -1e300 };
@@ -289,15 +290,15 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
         int axis = 0;
         for (int a = 1; a < 3; a++) if (h3[a] - l3[a] > h3[axis] - l3[axis]) axis = a;
         std::stable_sort(v.begin() + b0, v.begin() + e0, [&](int x, int y) { return spheres[x].center.e[axis] < spheres[y].center.e[axis]; });
-        const size_t groups = (cnt + 15) / 16;
-        const size_t left = std::min(cnt - 1, (groups / 2) * 16);    // a multiple of 16: only the last group of the scene is padded
+        const size_t groups = (cnt + G - 1) / G;
+        const size_t left = std::min(cnt - 1, (groups / 2) * G);     // a multiple of G: only the last group of the scene is padded
         split(v, b0, b0 + left);
         split(v, b0 + left, e0);
     };
     std::vector<int> slots;                                     // slot -> caller index, -1 = pad
     for (int k : big) slots.push_back(k);                       // big spheres first: groups [0, n_big_groups)
-    while (slots.size() % 16) slots.push_back(-1);
-    const int n_big_groups = (int)slots.size() / 16;
+    while (slots.size() % G) slots.push_back(-1);
+    const int n_big_groups = (int)slots.size() / G;
     if (!small.empty()) split(small, 0, small.size());
     for (int k : ordered) slots.push_back(k);
     while (slots.size() % 64) slots.push_back(-1);
@@ -306,7 +307,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     for (int a = 0; a < 3; a++) if (hi[a] > lo[a]) extent = std::max(extent, hi[a] - lo[a]);
     c.n_spheres = n;
     c.n_padded = (int)slots.size();
-    c.n_groups = c.n_padded / 16;
+    c.n_groups = c.n_padded / G;
     c.n_big_groups = n_big_groups;
     c.n_big = (int)big.size();
     c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));      // pad: radius 0, far away
@@ -329,7 +330,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     for (int g = n_big_groups; g < c.n_groups; g++) {
         double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
         int cnt = 0;
-        for (int s = g * 16; s < g * 16 + 16; s++) {
+        for (int s = g * G; s < g * G + G; s++) {
             if (slots[s] < 0) continue;
             cnt++;
             for (int a = 0; a < 3; a++) {
@@ -433,7 +434,7 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
         if (materials[k].type < RT_DIFFUSE || materials[k].type >= RT_MATERIAL_TYPE_COUNT) rt_fail("initRendererSpheres: bad material type");
     build_sphere_groups(spheres, materials, n);
     if (rt_sphere_kernel_lds_bytes(c.n_padded, n, 256) > 160 * 1024)
-        rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 3500 spheres)");
+        rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 2500 spheres)");
     if (c.n_groups > 256) rt_fail("initRendererSpheres: more than 256 sphere groups (the pair list stores the group in 8 bits)");
     common_init(cam, fb, nx, ny, maxDepth);
 }
