@@ -21,8 +21,8 @@
 //     Because a non-candidate returns FLT_MAX in the reference and never updates `closest`, and
 //     candidates are visited in increasing index with the same strict `<`, the result is
 //     bit-identical to the reference's linear scan;
-//   * sphere-group culling + pair compaction (scan_pairs): the host sorts the small spheres along a Morton curve
-//     into groups of 16 with an inflated AABB each; a ray only visits the groups whose box it enters before its
+//   * sphere-group culling + pair compaction (scan_pairs): the host splits the small spheres at medians
+//     into compact groups of 16 with an inflated AABB each; a ray only visits the groups whose box it enters before its
 //     current closest hit, and the (ray, group) pairs of a wave are compacted so that all 64 lanes always work.
 //     A skipped sphere could only have produced t > closest (rejected by the reference) or FLT_MAX, so the result
 //     is unchanged; the explicit (t, original index) tie rule keeps the reference's first-index-wins order;
@@ -910,6 +910,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     int role = 2;
     if (nA > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
     int tier = 2;                       // tier of the lane's pixel (= role of the wave when it was fetched)
+    int pcls = kCostClasses;            // cost list the lane's pixel came from
+    // the first `chain_heavy` chain lists (the longest chains) are held `chain_heavy_cap` to a wave instead of kSparseRays:
+    // a sparse step costs ~2 us + 0.8 us per live ray, so fewer neighbours = a shorter chain
+    const int chain_heavy_cap = (chain_cfg >> 12) & 0x3, chain_heavy = (chain_cfg >> 14) & 0x3;
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -969,7 +973,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
             const bool hold0 = __ballot(have_pixel && tier == 0) != 0ull;
-            const int cap = (role == 0 || hold0) ? kSparseRays : 64;
+            const bool hold_heavy = __ballot(have_pixel && tier == 0 && pcls < chain_heavy) != 0ull;
+            int cap = 64;
+            if (role == 0 || hold0) cap = (chain_heavy_cap > 0 && (hold_heavy || !hold0)) ? chain_heavy_cap : kSparseRays;
             const int allowed = cap - (int)__popcll(live_m);
             if (allowed <= 0) break;
             const unsigned long long idle_m = ~live_m;
@@ -1007,6 +1013,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 const uint32_t pos = item / K;                       // position in the pixel order; the K chunks of a pixel are adjacent items
                 chunk = (int)(item - pos * K);
                 uint32_t p;
+                int grab_cls = kCostClasses;
                 if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
                 else {
                     // the n0 pixels of the heavy lists are spread evenly over the first `spread` queue positions (= the lanes in
@@ -1030,6 +1037,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     }
                     int c = 0;
                     for (int k = 1; k < kCostClasses; k++) if (q >= s_cls_pos[k]) c = k;
+                    grab_cls = c;
                     const uint32_t j = q - s_cls_pos[c];
                     const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
                     p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
@@ -1062,6 +1070,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     }
                     have_pixel = true;
                     tier = role;
+                    pcls = grab_cls;
                 }
             }
         }
@@ -1211,7 +1220,10 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     }
     // chain waves: wave 0 of every 2nd workgroup (256 waves); lanes above 10 rays per sample are boosted; chain lists = the
     // first kChainClasses (measured on C2: 256 waves / 10 / 3 is the optimum of a flat basin)
-    const int chain_cfg = 2 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
+    // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, 2 pixels to a wave (3 lists, all "heavy");
+    // lanes of normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin): 256 waves x 4 pixels 5040,
+    // 512 x 2: 5540, 512 x 3: 5560, 1024 x 2: 5510, 1024 x 1: 5320 Msamples/s.
+    const int chain_cfg = 1 | (1 << 8) | (2 << 12) | (3 << 14) | (10 << 16) | (kChainClasses << 24);
     auto launch_queue = [&](const RtSphereParams& q, int classified) {
         const dim3 grid((unsigned)blocks), block(kThreads);
         if (legacy) hipLaunchKernelGGL((k_render_spheres_queue<true, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);

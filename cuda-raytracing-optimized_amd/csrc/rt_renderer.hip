@@ -245,7 +245,7 @@ void common_init(const rt_camera& cam, rt_vec3** fb, int nx, int ny, int maxDept
 // Device layout of a sphere scene.  The spheres are re-ordered into SLOTS, kSphereGroup (G) slots per group:
 //   * "big" spheres (radius > 4 x the median radius: the ground and the three unit spheres of the benchmark scene)
 //     come first; their groups are always scanned, by every lane, and give each ray a first `closest`;
-//   * "small" spheres are sorted along a 3D Morton curve so that consecutive slots are neighbours in space; each
+//   * "small" spheres are split recursively at medians so that the G slots of a group are neighbours in space; each
 //     group of G gets an axis-aligned bounding box, inflated well beyond fp32 rounding (1 % + 1e-4 of the scene
 //     extent), which the kernel uses to skip the group for rays that cannot reach it before their current hit;
 //   * pad slots fill the last group of each class and the tail up to a multiple of 64 slots; they carry
