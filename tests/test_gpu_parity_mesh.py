@@ -219,3 +219,18 @@ def test_sentinel_in_the_middle_of_a_leaf(rt, O):
         got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 12, nee=0, counters=1, variant=variant)
         assert np.array_equal(_bits(got), _bits(ref)), variant
         assert (st.rays, st.node_visits, st.prim_tests) == (cnt.rays, cnt.node_visits, cnt.prim_tests), variant
+
+
+def test_larger_staircase_frame_bit_exact(rt, O):
+    """A denser staircase (detail 2) at 320x180x4 spp, depth 64, Russian roulette on, NEE off (exact): the persistent kernel with
+    all lanes busy for many iterations, queue refills, thresholded traversal and pair rounds, against the oracle's full frame."""
+    tris, mats = rt.scene_staircase_procedural(2)
+    hm = rt.HostMesh.build(tris, 5)
+    nx, ny, ns = 320, 180, 4
+    cam = rt.staircase_camera(nx, ny)
+    o = O.default_options(False)
+    o.nee = 0
+    ref, cnt = O.render(O.mesh_scene(hm, mats), cam, o, nx, ny, ns, 64, counters=True)
+    got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, nee=0, counters=1)
+    assert np.array_equal(_bits(got), _bits(ref)), f"{np.count_nonzero(_bits(got) != _bits(ref))} differing words"
+    assert (st.rays, st.node_visits, st.prim_tests) == (cnt.rays, cnt.node_visits, cnt.prim_tests)

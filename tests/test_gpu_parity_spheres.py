@@ -87,6 +87,26 @@ def test_full_size_crop_bit_exact(rt, O):
     assert st.samples == nx * ny * ns
 
 
+def test_headline_frame_bit_exact_on_crops_and_random_pixels(rt, O):
+    """THE benchmark frame (BASELINE config 2: 1200x800, 488 spheres, 100 spp, depth 50) exactly as bench.py renders it -
+    two dispatches, cost lists, chain waves, boosts - against the oracle on five 32x16 crops (two of them over the pixels
+    with the longest chains of the frame, 3500-3700 rays each) and on 300 random single pixels."""
+    nx, ny, ns = 1200, 800, 100
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50)
+    assert not np.isnan(got).any()
+    sc = O.sphere_scene(sp, mt)
+    opt = O.default_options(True)
+    for (x0, y0) in ((728, 300), (1040, 344), (0, 0), (584, 392), (1168, 784)):
+        ref, _ = O.render(sc, cam, opt, nx, ny, ns, 50, region=(x0, y0, x0 + 32, y0 + 16))
+        assert np.array_equal(_bits(got[y0:y0 + 16, x0:x0 + 32]), _bits(ref[y0:y0 + 16, x0:x0 + 32])), (x0, y0)
+    rng = np.random.default_rng(2026)
+    for x, y in zip(rng.integers(0, nx, 300), rng.integers(0, ny, 300)):
+        ref, _ = O.render(sc, cam, opt, nx, ny, ns, 50, region=(int(x), int(y), int(x) + 1, int(y) + 1))
+        assert np.array_equal(_bits(got[y, x]), _bits(ref[y, x])), (x, y)
+    assert st.samples == nx * ny * ns
+
+
 def test_tinted_glass_and_fuzzy_metal_bit_exact(rt, O):
     """Materials the benchmark scene does not contain: tinted glass (throughput * tint on the reflected
     branch only, material.h:80-82) and a strongly fuzzed metal."""
