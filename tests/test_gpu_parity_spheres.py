@@ -142,18 +142,20 @@ def test_fast_mode_within_tolerance(rt, O):
 
 def test_stripe_partition_is_invisible(rt, O):
     """Interleaved row stripes (multi-GPU partition) must not change a single bit: render the image as
-    two partition members in turn on the one GPU and interleave."""
-    nx, ny, ns = 200, 120, 2
+    the members of a 2- and a 3-way partition in turn on the one GPU and interleave.  ns = 10 takes the two-dispatch
+    cost-ordered path inside every member (whose cost windows then straddle stripe boundaries: scheduling only)."""
+    nx, ny = 200, 120
     sp, mt, cam = rt.scene_random_spheres(nx, ny)
-    whole, _ = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50)
-    parts = [_render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, part_rank=r, part_world=2, stripe_rows=16)[0] for r in range(2)]
-    merged = np.zeros_like(whole)
-    for r in range(2):
-        for k in range(r, (ny + 15) // 16, 2):
-            merged[k * 16:(k + 1) * 16] = parts[r][k * 16:(k + 1) * 16]
-    assert np.array_equal(_bits(merged), _bits(whole))
-    # rows a member does not own stay untouched (zero)
-    assert not parts[0][16:32].any() and not parts[1][0:16].any()
+    for ns, world, rows in ((2, 2, 16), (10, 2, 16), (10, 3, 8)):
+        whole, _ = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50)
+        parts = [_render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, part_rank=r, part_world=world, stripe_rows=rows)[0] for r in range(world)]
+        merged = np.zeros_like(whole)
+        for r in range(world):
+            for k in range(r, (ny + rows - 1) // rows, world):
+                merged[k * rows:(k + 1) * rows] = parts[r][k * rows:(k + 1) * rows]
+        assert np.array_equal(_bits(merged), _bits(whole)), (ns, world, rows)
+        # rows a member does not own stay untouched (zero)
+        assert not parts[0][rows:2 * rows].any() and not parts[1][0:rows].any()
 
 
 def test_rerun_is_deterministic(rt):
