@@ -202,7 +202,8 @@ def main():
                          "flops_per_launch": flops_per_launch,
                          "note": "one frame = one 'launch' here: with the reference RNG stream the persistent kernel is dispatched "
                                  "twice per frame (first 2 samples, then the cost-ordered rest) and kernel_ms_avg / traffic are "
-                                 "the sums over both. fp32 VALU bound (no MFMA; algorithmic HBM bytes = 11.5 MB framebuffer per frame). achieved = "
+                                 "the sums over both. fp32 VALU bound: no GEMM shape, no MFMA (157.3 TFLOP/s is also the dense fp32 MFMA peak of "
+                                 "MI355X, so frac is the same under either label); algorithmic HBM bytes = 11.5 MB framebuffer per frame. achieved = "
                                  "algorithmic flops of the reference's brute-force scan, rays x (18 x 488 + 80) with rays counted "
                                  "on the GPU (bit-equal to the oracle's count), / kernel time; the kernel's exact group culling "
                                  "executes only executed_sphere_tests_per_ray of the 488 tests per ray"},
