@@ -987,7 +987,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             // lane-group would saturate the counter, so a wave reserves 128 at a time into a wave-local pool.
             const uint32_t cnt = (uint32_t)__popcll(need);
             if (pool_next >= pool_end) {
-                const uint32_t grab = (K > 1u) ? max(cnt, 128u) : cnt;
+                // (phase 1 hands out 960 k two-sample items in a millisecond: pooled too, or the one counter serialises)
+                const uint32_t grab = (K > 1u || P.phase == 1) ? max(cnt, 128u) : cnt;
                 const uint32_t limit = role == 0 ? nA : total;
                 uint32_t b = 0;
                 if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : 0), grab);
