@@ -787,7 +787,9 @@ __device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr
         }
     }
     // e = 16 x (rays per sample); >= 16 always (every sample starts with one ray)
-    const uint32_t e = (sum * 16u) / (cnt * (uint32_t)P.s_split);
+    // the window mean under-rates an isolated long pixel (its neighbours miss the glass): never below 3/4 of the pixel's own rate
+    const uint32_t own = (P.px_rays[(size_t)lr * P.nx + i] * 12u) / (uint32_t)P.s_split;
+    const uint32_t e = max((sum * 16u) / (cnt * (uint32_t)P.s_split), own);
     const uint32_t lim[kCostClasses - 1] = { 320u, 240u, 192u, 160u, 128u, 96u, 72u, 56u, 44u, 36u, 30u, 26u, 22u, 19u, 18u, 17u };
     int cls = kCostClasses - 1;
 #pragma unroll
