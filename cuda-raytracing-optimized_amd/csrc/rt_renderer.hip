@@ -434,7 +434,7 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
         if (materials[k].type < RT_DIFFUSE || materials[k].type >= RT_MATERIAL_TYPE_COUNT) rt_fail("initRendererSpheres: bad material type");
     build_sphere_groups(spheres, materials, n);
     if (rt_sphere_kernel_lds_bytes(c.n_padded, n, 256) > 160 * 1024)
-        rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 2500 spheres)");
+        rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 2100 spheres)");
     if (c.n_groups > 256) rt_fail("initRendererSpheres: more than 256 sphere groups (the pair list stores the group in 8 bits)");
     common_init(cam, fb, nx, ny, maxDepth);
 }

@@ -344,3 +344,35 @@ def test_preset_materials_in_a_frame(rt, O):
     got, _ = _render_gpu(rt, sp, m2, cam, nx, ny, ns, 50)
     rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
     assert rel.mean() >= 0.995, rel.mean()
+
+
+def test_scene_size_limits(rt, O):
+    """A scene near the LDS capacity (2100 spheres: one 8-wave workgroup per CU), one beyond it (4000) and an empty one:
+    the two refusals follow the kernels.cu:27-38 convention - message on stderr, exit(99) - instead of a launch failure."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    nx, ny, ns = 96, 64, 9
+    cam = rt.make_camera((9, 3, 7), (0, 0, 0), (0, 1, 0), 35.0, nx / ny, 0.05, 10.0)
+    for n in (2100,):
+        sp = np.zeros(n, rt.sphere_dtype)
+        mt = np.zeros(n, rt.material_dtype)
+        sp["center"] = rng.uniform(-20, 20, (n, 3)) * (1, 0.2, 1)
+        sp["radius"] = rng.uniform(0.1, 0.4, n)
+        mt["type"] = rng.integers(0, 3, n)
+        mt["color"] = rng.uniform(0.1, 1, (n, 3))
+        mt["param"] = np.where(mt["type"] == rt.RT_GLASS, 1.5, 0.1)
+        mt["texId"] = -1
+        ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 20)
+        got, _ = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 20)
+        assert np.array_equal(_bits(got), _bits(ref)), n
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); import cuda_raytracing_optimized_amd as rt; "
+            "sp = np.zeros(4000, rt.sphere_dtype); sp['radius'] = 0.1; mt = np.zeros(4000, rt.material_dtype); mt['texId'] = -1; "
+            "cam = rt.make_camera((9, 3, 7), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.05, 10.0); "
+            "rt.initRendererSpheres(sp, mt, cam, 96, 64, 20)" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 99 and "does not fit" in r.stderr, (r.returncode, r.stderr[-300:])
+    r = subprocess.run([sys.executable, "-c", code.replace("4000", "0")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 99 and "empty scene" in r.stderr, (r.returncode, r.stderr[-300:])
