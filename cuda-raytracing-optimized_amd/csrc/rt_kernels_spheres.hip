@@ -797,23 +797,37 @@ __device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr
     return cls;
 }
 
+__device__ __forceinline__ uint32_t coprime_stride_of(uint32_t n) {   // ~0.618 n, coprime with n
+    if (n <= 64u) return 1u;
+    uint32_t c = ((uint32_t)((unsigned long long)n * 2654435769ull >> 32)) | 1u;
+    for (;;) {
+        uint32_t a = c, b = n;
+        while (b) { const uint32_t t = a % b; a = b; b = t; }
+        if (a == 1u) break;
+        c += 2u;
+    }
+    return c % n;
+}
+
 // Each workgroup owns a contiguous range of pixel slots, counts its classes in LDS and touches the global counters once
 // per class (a global atomic per wave and class would serialise on 12 addresses: 1.7 ms instead of 40 us).
 constexpr int kOrderBlocks = 1024;
 
 template <int PASS>
 __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams P) {
-    __shared__ uint32_t s_cnt[kCostClasses], s_base[kCostClasses];
+    __shared__ uint32_t s_cnt[kCostClasses], s_base[kCostClasses], s_start[kCostClasses], s_n[kCostClasses], s_stride[kCostClasses];
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
     const uint32_t per = ((total + gridDim.x - 1u) / gridDim.x + (uint32_t)kThreads - 1u) / (uint32_t)kThreads * (uint32_t)kThreads;
     const uint32_t first = blockIdx.x * per, last = min(first + per, total);
+    uint32_t packed = 0;                                             // (local row << 16) | column of the pixel class_of() looked at
     auto class_of = [&](uint32_t p) {
         const uint32_t tile = p >> 6, within = p & 63u;
         const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
         const int i = tx * 8 + (int)(within & 7u);
         const int lr = ty * 8 + (int)(within >> 3);
+        packed = ((uint32_t)lr << 16) | (uint32_t)i;
         return (p < last && i < P.nx && lr < P.part.local_rows) ? cost_class(P, i, lr) : -1;
     };
     if (threadIdx.x < kCostClasses) s_cnt[threadIdx.x] = 0u;
@@ -827,16 +841,27 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
         if (threadIdx.x < kCostClasses && s_cnt[threadIdx.x]) atomicAdd(P.queue + 4 + threadIdx.x, s_cnt[threadIdx.x]);
         return;
     }
+    // The list entries are written where the render kernel will read them: position = start + (rank x stride) mod n, the
+    // multiplicative permutation that scatters neighbouring pixels over different waves (stride ~ 0.618 n, coprime with n;
+    // 1 for the last, sky list), and hold the pixel as (local row << 16 | column) - so that fetching a pixel costs the render
+    // kernel one load, not a 64-bit modulo and a division by the tile count.
     if (threadIdx.x < kCostClasses) {
         uint32_t start = 0;                                          // first position of this list in P.order
         for (int c = 0; c < (int)threadIdx.x; c++) start += P.queue[4 + c];
-        s_base[threadIdx.x] = start + (s_cnt[threadIdx.x] ? atomicAdd(P.queue + 4 + kCostClasses + threadIdx.x, s_cnt[threadIdx.x]) : 0u);
+        const uint32_t n = P.queue[4 + threadIdx.x];
+        s_start[threadIdx.x] = start;
+        s_n[threadIdx.x] = n;
+        s_stride[threadIdx.x] = ((int)threadIdx.x == kCostClasses - 1) ? 1u : coprime_stride_of(n);
+        s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(P.queue + 4 + kCostClasses + threadIdx.x, s_cnt[threadIdx.x]) : 0u;   // first rank of this workgroup
         s_cnt[threadIdx.x] = 0u;
     }
     __syncthreads();
     for (uint32_t p = first + threadIdx.x; p < last; p += kThreads) {
         const int cls = class_of(p);
-        if (cls >= 0) P.order[s_base[cls] + atomicAdd(&s_cnt[cls], 1u)] = p;
+        if (cls >= 0) {
+            const uint32_t rank = s_base[cls] + atomicAdd(&s_cnt[cls], 1u);
+            P.order[s_start[cls] + (uint32_t)(((unsigned long long)rank * s_stride[cls]) % s_n[cls])] = packed;
+        }
     }
 }
 
@@ -865,24 +890,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     // first, then the other lists in order; inside a list the order is scattered, except the last (sky) list.
     __shared__ uint32_t s_cls_base[kCostClasses], s_cls_pos[kCostClasses + 1], s_cls_stride[kCostClasses];
     const int n_cls = classified == 2 ? kCostClasses : (classified == 1 ? 3 : 0);
-    auto coprime_stride = [](uint32_t n) {                           // ~0.618 n, coprime with n
-        if (n <= 64u) return 1u;
-        uint32_t c = ((uint32_t)((unsigned long long)n * 2654435769ull >> 32)) | 1u;
-        for (;;) {
-            uint32_t a = c, b = n;
-            while (b) { const uint32_t t = a % b; a = b; b = t; }
-            if (a == 1u) break;
-            c += 2u;
-        }
-        return c % n;
-    };
     if (threadIdx.x == 0) {
         uint32_t pos = 0;
         for (int c = 0; c < n_cls; c++) {
             const uint32_t n = P.queue[4 + c];
             s_cls_base[c] = classified == 2 ? pos : (uint32_t)c * padded;
             s_cls_pos[c] = pos;
-            s_cls_stride[c] = (c == n_cls - 1) ? 1u : coprime_stride(n);
+            s_cls_stride[c] = (c == n_cls - 1) ? 1u : coprime_stride_of(n);
             pos += n;
         }
         for (int c = n_cls; c <= kCostClasses; c++) s_cls_pos[c] = pos;
@@ -1042,13 +1056,23 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     for (int k = 1; k < kCostClasses; k++) if (q >= s_cls_pos[k]) c = k;
                     grab_cls = c;
                     const uint32_t j = q - s_cls_pos[c];
-                    const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
-                    p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
+                    if (classified == 2) {
+                        p = P.order[s_cls_base[c] + j];              // already permuted, already (row << 16 | column): k_order_by_cost
+                    } else {
+                        const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
+                        p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
+                    }
                 }
-                const uint32_t tile = p >> 6, within = p & 63u;
-                const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
-                const int i = tx * 8 + (int)(within & 7u);
-                lr = ty * 8 + (int)(within >> 3);
+                int i;
+                if (classified == 2) {
+                    i = (int)(p & 0xFFFFu);
+                    lr = (int)(p >> 16);
+                } else {
+                    const uint32_t tile = p >> 6, within = p & 63u;
+                    const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
+                    i = tx * 8 + (int)(within & 7u);
+                    lr = ty * 8 + (int)(within >> 3);
+                }
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
                     if (P.phase == 0) {
                         s_end = min(P.ns, (chunk + 1) * P.spw);
@@ -1240,7 +1264,8 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // samples, then resume all pixels longest-first (see k_classify_by_cost).  Otherwise: one launch, optionally ordered
     // by the centre-ray pre-pass (k_classify_spheres: order_mode 3) or plainly scattered (2) / tile-major (1).
     const int split = 2;                                             // measured: 2 -> 24.5 ms, 4 -> 24.8, 6 -> 25.4
-    if (order_mode == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8) {
+    if (order_mode == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8 &&
+        p.nx <= 65535 && p.part.local_rows <= 65535) {                                   // list entries pack (row << 16 | column)
         RtSphereParams q = p;
         q.phase = 1; q.s_split = split;
         e = launch_queue(q, 0);
