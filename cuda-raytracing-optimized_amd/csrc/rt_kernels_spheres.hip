@@ -501,70 +501,93 @@ __device__ __forceinline__ void sparse_test_slot(const RtSphereParams& P, const 
     }
 }
 
+// All live rays (1..16 of them) are handled TOGETHER: the work items of a phase - (ray, big slot), (ray, group box),
+// (reachable (ray, group) pair, sphere of the group) - are numbered across the rays and dealt to the 64 lanes, 64 at a time;
+// a lane fetches the ray of its item from the wave's LDS ray table.  Two rays therefore cost three lane passes like one
+// ray does (16 + 16 big slots, 31 + 31 boxes, ~2 x 16 spheres), where handling the rays one after the other cost six.
 __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, unsigned long long live,
                                            bool cull) {
     const int lane = threadIdx.x & 63;
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
-    unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
-    w_best[lane] = ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r at w_ray[2r], w_ray[2r + 1]
+    unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);   // best key of ray r at w_best[r]
+    unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);  // reachable (ray << 8 | group) pairs
+    const bool mine = ((live >> lane) & 1ull) != 0ull;
+    const int m = (int)__popcll(live);                               // rays (wave-uniform)
+    const int my_r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+    if (mine) {
+        w_ray[2 * my_r] = make_float4(org.x, org.y, org.z, a);
+        w_ray[2 * my_r + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
+        w_best[my_r] = ~0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (unsigned long long m = live; m; m &= m - 1) {
-        const int q = __builtin_ctzll(m);                            // wave-uniform
-        const f3 O = F3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.x), q)),
-                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.y), q)),
-                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org.z), q)));
-        const f3 D = F3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.x), q)),
-                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.y), q)),
-                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dn.z), q)));
-        const float A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), q));
-        // (a) big spheres: one slot per lane
-        for (int s0 = 0; s0 < (P.n_big_groups << kSphereGroupShift); s0 += 64)
-            if (s0 + lane < (P.n_big_groups << kSphereGroupShift)) sparse_test_slot(P, S, s0 + lane, O, D, A, &w_best[q]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float closest = __uint_as_float((uint32_t)(w_best[q] >> 32));      // FLT_MAX-or-larger bit pattern if none: keeps everything
-        const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));   // conservative test: 1 ulp is fine
-        // (b) one group box per lane, (c) 4 reachable groups per step, 16 lanes each
-        for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += 64) {
-            const int g = g0 + lane;
-            bool reach = false;
-            if (g < P.n_groups) {
-                if (!cull) {
-                    reach = true;
-                } else {
-                    const float4 lo = S.grp[2 * g], hi = S.grp[2 * g + 1];
-                    const float x0 = (lo.x - O.x) * inv.x, x1 = (hi.x - O.x) * inv.x;
-                    const float y0 = (lo.y - O.y) * inv.y, y1 = (hi.y - O.y) * inv.y;
-                    const float z0 = (lo.z - O.z) * inv.z, z1 = (hi.z - O.z) * inv.z;
-                    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                    reach = !((t_in > t_out) || (t_out < 0.0f) || (t_in * 0.99999f - 1.0e-4f > closest));
-                }
-            }
-            unsigned long long gm = __ballot(reach);
-            while (gm) {
-                int gsel = -1;                                       // this lane's group: the (lane>>4)-th of the next 4 set bits
-#pragma unroll
-                for (int w = 0; w < 64 / kSphereGroup; w++) {
-                    if (gm) {
-                        const int gb = __builtin_ctzll(gm);
-                        gm &= gm - 1;
-                        if ((lane >> kSphereGroupShift) == w) gsel = g0 + gb;
-                    }
-                }
-                if (gsel >= 0) sparse_test_slot(P, S, (gsel << kSphereGroupShift) + (lane & (kSphereGroup - 1)), O, D, A, &w_best[q]);
-            }
+    // (a) big spheres: items (ray, slot)
+    const int nbs = P.n_big_groups << kSphereGroupShift;
+    for (int base = 0; base < m * nbs; base += 64) {
+        const int w = base + lane;
+        if (w < m * nbs) {
+            const int r = w / nbs, sl = w - r * nbs;
+            const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
+            sparse_test_slot(P, S, sl, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, &w_best[r]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const unsigned long long key = w_best[lane];
+    // (b) group boxes: items (ray, group); the reachable ones are appended to the pair list
+    const int ng = P.n_groups - P.n_big_groups;
+    int np = 0;                                                      // pairs in the list (wave-uniform)
+    for (int base = 0; base < m * ng; base += 64) {
+        const int w = base + lane;
+        bool reach = false;
+        int r = 0, g = 0;
+        if (w < m * ng) {
+            r = w / ng;
+            g = P.n_big_groups + (w - r * ng);
+            if (!cull) {
+                reach = true;
+            } else {
+                const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
+                const float closest = __uint_as_float((uint32_t)(w_best[r] >> 32));   // FLT_MAX-or-larger bit pattern if none: keeps everything
+                const f3 inv = F3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));   // conservative test: 1 ulp is fine
+                const float4 lo = S.grp[2 * g], hi = S.grp[2 * g + 1];
+                const float x0 = (lo.x - ro.x) * inv.x, x1 = (hi.x - ro.x) * inv.x;
+                const float y0 = (lo.y - ro.y) * inv.y, y1 = (hi.y - ro.y) * inv.y;
+                const float z0 = (lo.z - ro.z) * inv.z, z1 = (hi.z - ro.z) * inv.z;
+                const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                reach = !((t_in > t_out) || (t_out < 0.0f) || (t_in * 0.99999f - 1.0e-4f > closest));
+            }
+        }
+        const unsigned long long rm = __ballot(reach);
+        if (reach) {
+            const int at = np + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+            w_pair[at] = (unsigned short)((r << 8) | g);
+        }
+        np += (int)__popcll(rm);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (c) the spheres of the reachable pairs: items (pair, sphere of the group)
+    for (int base = 0; base < (np << kSphereGroupShift); base += 64) {
+        const int w = base + lane;
+        if (w < (np << kSphereGroupShift)) {
+            const unsigned pr = w_pair[w >> kSphereGroupShift];
+            const int r = (int)(pr >> 8), g = (int)(pr & 0xFFu);
+            const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
+            sparse_test_slot(P, S, (g << kSphereGroupShift) + (w & (kSphereGroup - 1)), F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, &w_best[r]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     Hit out = { FLT_MAX, -1, 0x7fffffff };
-    if (((live >> lane) & 1ull) && key != ~0ull) {
-        out.closest = __uint_as_float((uint32_t)(key >> 32));
-        out.orig = (int)(uint32_t)key;
-        out.sid = S.slot_of[out.orig];
+    if (mine) {
+        const unsigned long long key = w_best[my_r];
+        if (key != ~0ull) {
+            out.closest = __uint_as_float((uint32_t)(key >> 32));
+            out.orig = (int)(uint32_t)key;
+            out.sid = S.slot_of[out.orig];
+        }
     }
     return out;
 }
@@ -620,7 +643,9 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
     const unsigned long long live = __ballot(has_ray);
     lap(0);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
-        if (__popcll(live) <= sparse_max && coop_below == -1) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
+        // (the sparse form lists its reachable (ray, group) pairs in the wave's pair list: rays x groups must fit it)
+        if (__popcll(live) <= sparse_max && coop_below == -1 &&
+            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= 64 * kPassGroups + 64) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
         else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
