@@ -1272,10 +1272,10 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     }
     // chain waves: wave 0 of every 2nd workgroup (256 waves); lanes above 10 rays per sample are boosted; chain lists = the
     // first kChainClasses (measured on C2: 256 waves / 10 / 3 is the optimum of a flat basin)
-    // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, 2 pixels to a wave (3 lists, all "heavy");
-    // lanes of normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin): 256 waves x 4 pixels 5040,
-    // 512 x 2: 5540, 512 x 3: 5560, 1024 x 2: 5510, 1024 x 1: 5320 Msamples/s.
-    const int chain_cfg = 1 | (1 << 8) | (2 << 12) | (3 << 14) | (10 << 16) | (kChainClasses << 24);
+    // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
+    // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
+    // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
+    const int chain_cfg = 1 | (1 << 8) | (0 << 12) | (3 << 14) | (10 << 16) | (kChainClasses << 24);
     auto launch_queue = [&](const RtSphereParams& q, int classified) {
         const dim3 grid((unsigned)blocks), block(kThreads);
         if (legacy) hipLaunchKernelGGL((k_render_spheres_queue<true, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
