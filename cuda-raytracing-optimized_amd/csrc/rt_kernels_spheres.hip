@@ -937,7 +937,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     const uint32_t n_rest = total_px - n0;
     const uint32_t K = (uint32_t)P.chunks;                           // work items per pixel (1 unless RT_RNG_COUNTER)
     const uint32_t total = total_px * K;
-    const uint32_t spread = gridDim.x * (uint32_t)kThreads;          // lanes in flight
+    // lanes that draw from the general queue at t = 0: all, minus the chain waves (which start on the chain lists)
+    uint32_t spread = gridDim.x * (uint32_t)kThreads;
+    if (nA > 0u) spread -= ((gridDim.x + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u;
     const bool spread_ok = n0 > 0u && n0 <= spread && (spread - n0) <= n_rest;
     // Chain waves.  A lane that is not boosted advances ONE ray per wave iteration, and an iteration takes 3-4 us for <= 4
     // live lanes (sparse form) but 15-25 us for 64: a pixel handed out at time T ends near T + rays x iteration time, and
