@@ -156,6 +156,12 @@ def test_stripe_partition_is_invisible(rt, O):
         assert np.array_equal(_bits(merged), _bits(whole)), (ns, world, rows)
         # rows a member does not own stay untouched (zero)
         assert not parts[0][rows:2 * rows].any() and not parts[1][0:rows].any()
+    # more members than stripes: members 1..3 own nothing, render nothing and return (no hang, no fault)
+    nx, ny, ns = 40, 8, 9
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    whole, _ = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50)
+    parts = [_render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, part_rank=r, part_world=4, stripe_rows=8)[0] for r in range(4)]
+    assert np.array_equal(_bits(parts[0]), _bits(whole)) and not any(p.any() for p in parts[1:])
 
 
 def test_rerun_is_deterministic(rt):
