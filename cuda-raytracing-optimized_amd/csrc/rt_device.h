@@ -192,17 +192,13 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
 
     if (bsdf == B_COAT) bsdf = fresnel_layer(normal, inside, wo, ior, rng) ? B_GLOSSY : B_DIFFUSE;     // material.h:62-70
 
-    if (bsdf == B_DIFFUSE) {                                 // diffuse_bsdf, material.h:27-31
-        v = normal + random_in_unit_sphere(rng);
-        thr = albedo;
-        specular = false;
-    } else if (bsdf == B_GLOSSY) {                           // glossy_bsdf, material.h:46-53 (throughput 1 * tint == tint)
-        v = reflect(wo, normal);
-        if (fuzz > 0.0001f) v = v + fuzz * random_in_unit_sphere(rng);
-        thr = tint;
-    } else {
-        // dielectric_bsdf (material.h:73-92) / subsurface_dielectric_bsdf (:119-143)
-        bool scattered = false;
+    // Lanes of different materials reach their random_in_unit_sphere draw (diffuse bounce, metal fuzz, subsurface event) in
+    // different branches; a wave would run the rejection loop once per branch (max-over-lanes iterations each time).  The
+    // draw is hoisted to ONE place: everything a lane draws BEFORE it (coat layer above, subsurface distance here) is
+    // done first, what it draws after it (Fresnel choice of the dielectrics) comes after - every lane's own draw order
+    // is the reference's.
+    bool scattered = false;
+    if (bsdf == B_DIELECTRIC || bsdf == B_SSS) {             // dielectric_bsdf (material.h:73-92) / subsurface_dielectric_bsdf (:119-143)
         if (inside) {
             if (bsdf == B_SSS) {
                 const float d = -logf(rnd(rng)) / 2.0f;      // scatteringDistance 2.0 (scene_materials.h:91)
@@ -214,16 +210,27 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
                 thr = F3(expf(e.x), expf(e.y), expf(e.z));
             }
         }
-        if (scattered) {
-            v = random_in_unit_sphere(rng);
-            normalise = false;                               // material.h:128: wi is NOT normalised
-        } else if (fresnel_layer(normal, inside, wo, ior, rng)) {
-            v = reflect(wo, normal);                         // glossy_bsdf, fuzz 0
-            thr = thr * tint;
-        } else {
-            v = refract(wo, normal, inside ? ior : (1.0f / ior));
-            refracted = true;
-        }
+    }
+    f3 rs = F3(0, 0, 0);
+    if (bsdf == B_DIFFUSE || (bsdf == B_GLOSSY && fuzz > 0.0001f) || scattered) rs = random_in_unit_sphere(rng);
+
+    if (bsdf == B_DIFFUSE) {                                 // diffuse_bsdf, material.h:27-31
+        v = normal + rs;
+        thr = albedo;
+        specular = false;
+    } else if (bsdf == B_GLOSSY) {                           // glossy_bsdf, material.h:46-53 (throughput 1 * tint == tint)
+        v = reflect(wo, normal);
+        if (fuzz > 0.0001f) v = v + fuzz * rs;
+        thr = tint;
+    } else if (scattered) {
+        v = rs;
+        normalise = false;                                   // material.h:128: wi is NOT normalised
+    } else if (fresnel_layer(normal, inside, wo, ior, rng)) {
+        v = reflect(wo, normal);                             // glossy_bsdf, fuzz 0
+        thr = thr * tint;
+    } else {
+        v = refract(wo, normal, inside ? ior : (1.0f / ior));
+        refracted = true;
     }
     out.wi = normalise ? unit(v) : v;
     out.throughput = thr;
