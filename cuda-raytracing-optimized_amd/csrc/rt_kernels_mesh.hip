@@ -360,6 +360,11 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
     const bool dbg = DBG && P.dbg != nullptr;       // DBG = false: the diagnostics (and their SGPR pressure) compile away
 
+    // A lane needs a new ray job in four places (new sample, new pixel, next bounce, shadow ray); job_start (ray set-up with
+    // three IEEE divides + the scene-bounds test) is called at ONE place for all of them, after PROCESS and the refill:
+    // as separate call sites a wave ran it once per place.  1 = closest-hit ray along `dir`, 2 = shadow ray along `shadow_dir`.
+    int want_job = 0;
+    f3 shadow_dir = F3(0, 0, 1);
     auto start_sample = [&]() {                                      // kernels.cu:549-555, 397-398
         if (P.rng_mode == RT_RNG_COUNTER) rng = sample_seed(pixelId, (uint32_t)s);
         const float u = ((float)pi + rnd(rng)) / (float)P.nx;
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
         inside = false;
         specular = false;
         nrays++;
-        job_start(P, J, org, dir, eps, FLT_MAX, false);             // hit(context, p, FLT_MAX, false, ...)
+        want_job = 1;                                               // hit(context, p, FLT_MAX, false, ...)
     };
 
     while (true) {
@@ -437,7 +442,8 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                                 pend_contrib = (omega * (dotl * (atten * ld3(P.lightColor)))) / (float)M_PI;
                                 pend_dist = len(lightC - org) - lightR;
                                 nshadow++;
-                                job_start(P, J, org, shadowDir, eps, pend_dist, true);   // hit(context, p, lightDist, true, ...)
+                                shadow_dir = shadowDir;
+                                want_job = 2;                        // hit(context, p, lightDist, true, ...)
                                 shadow_job = true;
                             }
                         }
@@ -470,7 +476,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                 if (bounce >= P.max_depth) path_done = true;         // loop bound, kernels.cu:402
                 if (!path_done) {
                     nrays++;
-                    job_start(P, J, org, dir, eps, FLT_MAX, false);
+                    want_job = 1;
                 }
             }
             if (path_done) {
@@ -517,6 +523,11 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
             }
         }
         if (__ballot(have_pixel) == 0ull) break;
+        if (want_job) {
+            const bool sh = want_job == 2;
+            job_start(P, J, org, sh ? shadow_dir : dir, eps, sh ? pend_dist : FLT_MAX, sh);
+            want_job = 0;
+        }
         if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[1] += c1 - c0; c0 = c1; }
 
         // ================= TRAVERSE ================================================================================
