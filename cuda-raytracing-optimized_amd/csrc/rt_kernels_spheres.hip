@@ -149,12 +149,17 @@ __device__ __forceinline__ void start_sample(const RtSphereParams& P, Lane& L) {
     L.inside = false;
 }
 
-__device__ __forceinline__ void start_pixel(const RtSphereParams& P, Lane& L, int i, int j, int first_sample = 0) {
+// pixel state without its first sample (the caller starts it: start_sample)
+__device__ __forceinline__ void init_pixel(const RtSphereParams& P, Lane& L, int i, int j, int first_sample = 0) {
     L.i = i; L.j = j;
     L.pixelId = (uint32_t)(j * P.nx + i);                            // kernels.cu:541 (global id -> seed)
     L.rng = pixel_seed(L.pixelId);
     L.col = F3(0, 0, 0);
     L.s = first_sample;
+}
+
+__device__ __forceinline__ void start_pixel(const RtSphereParams& P, Lane& L, int i, int j, int first_sample = 0) {
+    init_pixel(P, L, i, j, first_sample);
     start_sample(P, L);
 }
 
@@ -979,12 +984,17 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     float dbg_grab = 0.0f, dbg_p1 = 0.0f;                           // this lane's pixel: time it was grabbed, rays of phase 1
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
-    auto finish = [&](bool fin) {
+    // A lane starts a sample in three situations: its previous path ended (finish), it fetched a new pixel, it resumed a
+    // parked one.  As three call sites a wave ran start_sample (lens sampling, renormalisation: ~180 instructions) up to three
+    // times per iteration; the lanes are flagged instead and ONE site after the refill starts them all.  Only a boosted
+    // wave starts the sample at once (`now`), because its heavy lanes trace again within the same iteration.
+    bool need_sample = false;
+    auto finish = [&](bool fin, bool now) {
         if (fin) {
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
             if (L.s < s_end) {
-                start_sample(P, L);
+                if (now) start_sample(P, L); else need_sample = true;
             } else {
                 if (P.phase == 1) {                                  // first samples done: park the pixel (RNG state, running sum, cost)
                     const size_t px = (size_t)lr * P.nx + L.i;
@@ -1103,11 +1113,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
                     if (P.phase == 0) {
                         s_end = min(P.ns, (chunk + 1) * P.spw);
-                        start_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
+                        init_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
+                        need_sample = true;
                         pix_rays = 0;
                     } else if (P.phase == 1) {
                         s_end = P.s_split;
-                        start_pixel(P, L, i, global_row(P.part, lr), 0);
+                        init_pixel(P, L, i, global_row(P.part, lr), 0);
+                        need_sample = true;
                         pix_rays = 0;
                     } else {                                         // resume: the pixel's stream continues where phase 1 left it
                         s_end = P.ns;
@@ -1120,7 +1132,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                         L.s = P.s_split;
                         pix_rays = P.px_rays[px];
                         if (wdbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
-                        start_sample(P, L);
+                        need_sample = true;
                     }
                     have_pixel = true;
                     tier = role;
@@ -1128,6 +1140,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 }
             }
         }
+        if (need_sample) { start_sample(P, L); need_sample = false; }
         const unsigned long long live_now = __ballot(have_pixel);
         if (DBG && wdbg) dbg_tm[7] += __builtin_amdgcn_s_memtime() - t_refill;
         if (live_now == 0ull) break;                                 // wave-uniform exit: idle lanes stay to help
@@ -1165,7 +1178,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             }
             const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr);
             if (DBG && wdbg) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
-            finish(done && sel);
+            finish(done && sel, steps > 1);
         }
     }
 
