@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     // three IEEE divides + the scene-bounds test) is called at ONE place for all of them, after PROCESS and the refill:
     // as separate call sites a wave ran it once per place.  1 = closest-hit ray along `dir`, 2 = shadow ray along `shadow_dir`.
     int want_job = 0;
+    bool need_sample = false;
     f3 shadow_dir = F3(0, 0, 1);
     auto start_sample = [&]() {                                      // kernels.cu:549-555, 397-398
         if (P.rng_mode == RT_RNG_COUNTER) rng = sample_seed(pixelId, (uint32_t)s);
@@ -483,7 +484,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                 col = col + pcolor;                                  // kernels.cu:558
                 s++;
                 if (s < P.ns) {
-                    start_sample();
+                    need_sample = true;
                 } else {
                     const f3 out = col / (float)P.ns;                // kernels.cu:568
                     float* dst = fbf + ((size_t)lr * P.nx + pi) * 3;
@@ -518,11 +519,12 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     col = F3(0, 0, 0);
                     s = 0;
                     have_pixel = true;
-                    start_sample();
+                    need_sample = true;
                 }
             }
         }
         if (__ballot(have_pixel) == 0ull) break;
+        if (need_sample) { start_sample(); need_sample = false; }    // one site for "path ended" and "new pixel"
         if (want_job) {
             const bool sh = want_job == 2;
             job_start(P, J, org, sh ? shadow_dir : dir, eps, sh ? pend_dist : FLT_MAX, sh);
