@@ -3,20 +3,32 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--fp parity|fast]
 
-A "step" is one full frame of the workload rendered through the C-ABI
-(initRendererSpheres once, then runRenderer per step; scene and camera already resident in HBM).
+A "step" is one full frame of the workload rendered through the C-ABI (init* once, then runRenderer
+per step; scene and camera already resident in HBM).
 
-  N = 1   BASELINE.json configs[1]: random-spheres (488 spheres), 1200x800, 100 spp, maxDepth 50.
-  N > 1   weak scaling: the same scene, 100 spp, 3:2 image whose AREA grows with N (~960 k pixels per
-          GPU); the image is cut into interleaved 8-row stripes, rank r renders stripes k = r (mod N)
-          (no collective on the data path) and the stripes are gathered on the host: the ranks share one
-          framebuffer in /dev/shm, page-locked by every rank, and each rank's device-to-host stripe copies
-          (hipMemcpy2DAsync inside runRenderer) land in it directly.  Launched by the driver as
-          `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+  N = 1   headline = BASELINE.json configs[1] (C2): random-spheres (488 spheres), 1200x800, 100 spp,
+          maxDepth 50.  The other single-GPU configs of BASELINE.json ride in the same JSON line under
+          "other_configs": C3 (1200x800x1000), C4 (staircase mesh 1920x1080x256 through initRenderer,
+          NEE + RR, with its own BVH-form roofline) and C5's workload (3840x2160x4096) on this one GPU.
+  N > 1   STRONG scaling of a FIXED image: BASELINE.json configs[4] (C5), random-spheres 3840x2160 at
+          4096 spp (34 G samples per step: 4.2 s on one GPU, ~0.5 s on eight).  The image is cut into
+          interleaved 8-row stripes, rank r renders stripes k = r (mod N) — no collective on the data
+          path — and the stripes are gathered on the host: the ranks share one framebuffer in /dev/shm,
+          page-locked by every rank, and each rank's device-to-host stripe copies (hipMemcpy2DAsync
+          inside runRenderer) land in it directly.  The same partitioned job on C2 (1200x800x100: 2 ms
+          of kernel per GPU at N = 8, i.e. launch + D2H) is recorded under "other_configs" for the
+          north star's "1200x800x100 at 1/2/4/8 GPUs", and rank 0 renders the whole C5 frame alone
+          once ("single_gpu_same_workload") so the line carries its own strong-scaling denominator.
+          Launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+
+run_job() below is THE partitioned job: stripe partition, shared host framebuffer, barrier-bracketed
+timing, max/sum over ranks.  tests/test_multigpu_gloo.py drives this same function on CPU (gloo,
+world size 2 and 3) with a backend that renders the stripes with the CPU oracle.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,53 +40,265 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SPP = 100
-MAX_DEPTH = 50
 N_SPHERES = 488
 PEAK_FP32_VALU_TFLOPS = 157.3       # MI355X vector fp32 peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)"
+PEAK_L2_GATHER_TBPS = 18.8          # same guide, "Indexed rows: gather into LDS": rows served from the XCDs' L2, chip-wide 16.8-18.8 TB/s
+PEAK_HBM_TBPS = 8.0
 FLOPS_PER_TEST = 18                 # sphereHit discriminant path with `a` hoisted
 FLOPS_PER_RAY = 80                  # per-ray set-up + shading
+FLOPS_PER_BOX = 20                  # slab test of one group box (15 flop + compares)
+
+# BASELINE.json configs[1..4]
+WORKLOADS = {
+    "C2": dict(kind="spheres", nx=1200, ny=800, spp=100, depth=50,
+               name="random-spheres (488 spheres, LCG seed 0) 1200x800 100spp maxDepth 50, gradient sky"),
+    "C3": dict(kind="spheres", nx=1200, ny=800, spp=1000, depth=50,
+               name="random-spheres (488 spheres) 1200x800 1000spp maxDepth 50"),
+    "C4": dict(kind="mesh", nx=1920, ny=1080, spp=256, depth=64, detail=4,
+               name="procedural staircase mesh (36380 triangles, 16384-node BVH, 5 per leaf) 1920x1080 256spp maxDepth 64, "
+                    "NEE + Russian roulette, constant sky (kernels.cu HEAD defaults) through initRenderer"),
+    "C5": dict(kind="spheres", nx=3840, ny=2160, spp=4096, depth=50,
+               name="random-spheres (488 spheres, LCG seed 0) 3840x2160 4096spp maxDepth 50, gradient sky"),
+}
 
 
-def measured_hbm_traffic():
-    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of THIS command
-    (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md).  bench.py cannot run the profiler around itself, so it reports the committed figure and
-    names its source; None if no summary is present."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_summary.txt")))
-    if not files:
-        return None, None
-    text = open(files[-1]).read()
-    f = re.search(r"^FETCH_SIZE\s+([0-9.e+]+)", text, re.M)
-    w = re.search(r"^WRITE_SIZE\s+([0-9.e+]+)", text, re.M)
-    if not (f and w):
-        return None, None
-    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(files[-1], ROOT)
+# ------------------------------------------------------------------------------------------------------
+# communication: torch.distributed (nccl = RCCL on the GPU box, gloo in the CPU tests) or nothing at N = 1
+# ------------------------------------------------------------------------------------------------------
+
+class LocalComm:
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def reduce(self, values, op):
+        return list(values)
 
 
-def cpu_baseline(rt, nx, ny):
+class DistComm:
+    """barrier + max/sum over ranks; the data path (the framebuffer) never goes through here."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def reduce(self, values, op):
+        import torch
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return t.tolist()
+
+
+# ------------------------------------------------------------------------------------------------------
+# backend: the HIP renderer behind the C-ABI.  (tests/test_multigpu_gloo.py has the CPU-oracle twin.)
+# ------------------------------------------------------------------------------------------------------
+
+class HipBackend:
+    def __init__(self, fp="parity", rng="reference", variant=0):
+        import cuda_raytracing_optimized_amd as rt
+        self.rt, self.fp, self.rng, self.variant = rt, fp, rng, variant
+        self.opt = None
+        self.w = None
+
+    def open(self, w, rank, world, shared_fb):
+        rt = self.rt
+        self.w = w
+        if w["kind"] == "spheres":
+            sp, mt, cam = rt.scene_random_spheres(w["nx"], w["ny"])
+            self.fb = rt.initRendererSpheres(sp, mt, cam, w["nx"], w["ny"], w["depth"])
+            self.opt = rt.getDefaultRenderOptions(True)
+        else:
+            tris, mats = rt.scene_staircase_procedural(w["detail"])
+            hm = rt.HostMesh.build(tris, 5)
+            cam = rt.staircase_camera(w["nx"], w["ny"])
+            ks, keep = rt.make_kernel_scene(hm, mats)
+            self.fb = rt.initRenderer(ks, cam, w["nx"], w["ny"], w["depth"], keepalive=keep)
+            self.opt = rt.getDefaultRenderOptions(False)
+        rt.setRenderOptions(self.opt, fp=rt.RT_FP_FAST if self.fp == "fast" else rt.RT_FP_PARITY,
+                            rng=rt.RT_RNG_COUNTER if self.rng == "counter" else rt.RT_RNG_REFERENCE_STREAM,
+                            variant=self.variant, part_rank=rank, part_world=world, stripe_rows=8)
+        if shared_fb is not None:
+            rt.setExternalFramebuffer(shared_fb)     # every rank's D2H stripe copies land in the one shared framebuffer
+
+    def step(self, spp=None):
+        self.rt.runRenderer(spp or self.w["spp"], 8, 8)      # blocking: kernel(s) + D2H of this rank's stripes = the host gather
+        return self.rt.getRenderStats().kernel_ms
+
+    def counted(self, spp):
+        """One untimed run with the device counters on: the inputs of the algorithmic work figures."""
+        rt = self.rt
+        rt.setRenderOptions(self.opt, counters=1)
+        rt.runRenderer(spp, 8, 8)
+        st = rt.getRenderStats()
+        rt.setRenderOptions(self.opt, counters=0)
+        return dict(rays=st.rays, exec_tests=st.exec_tests, node_visits=st.node_visits, prim_tests=st.prim_tests,
+                    box_tests=getattr(st, "box_tests", 0), shadow_rays=getattr(st, "shadow_rays", 0), spp=spp)
+
+    def device_sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def image(self):
+        return np.array(self.fb, copy=True)
+
+    def close(self):
+        self.rt.cleanupRenderer()
+
+
+# ------------------------------------------------------------------------------------------------------
+# THE job: partition -> (shared framebuffer) -> warm-up -> K timed steps between barriers -> max over ranks
+# ------------------------------------------------------------------------------------------------------
+
+def run_job(backend, comm, w, steps, warmup, tag="job", count_spp=None, warmup_spp=None, keep_image=False):
+    """Renders workload `w` `steps` times on comm.world ranks (interleaved 8-row stripes, host gather into one shared
+    framebuffer, no collective on the data path) and returns, on every rank, the whole-job figures:
+    elapsed = MAX over ranks of the barrier-bracketed wall time of the K steps, kernel_ms = MAX over ranks of the mean
+    HIP-event kernel time, counters = SUM over ranks, scaled from `count_spp` to the workload's spp."""
+    from cuda_raytracing_optimized_amd import multigpu
+    rank, world = comm.rank, comm.world
+    shared = None
+    if world > 1:
+        shared = multigpu.SharedFramebuffer(tag, w["nx"], w["ny"], rank, comm.barrier)
+    try:
+        backend.open(w, rank, world, shared.array if shared else None)
+        cnt = backend.counted(count_spp or w["spp"])
+        for _ in range(warmup):
+            backend.step(warmup_spp)
+        comm.barrier(); backend.device_sync()
+        t0 = time.perf_counter()
+        kernel_ms = []
+        for _ in range(steps):
+            kernel_ms.append(backend.step())
+        comm.barrier(); backend.device_sync()
+        elapsed = time.perf_counter() - t0
+        image = None
+        if keep_image:
+            comm.barrier()
+            image = np.array(shared.array) if shared else backend.image()
+        backend.close()
+    finally:
+        if shared:
+            shared.close(comm.barrier)
+    scale = w["spp"] / float(cnt["spp"])
+    keys = ("rays", "exec_tests", "node_visits", "prim_tests", "box_tests", "shadow_rays")
+    mx = comm.reduce([elapsed, float(np.mean(kernel_ms))], "max")
+    sm = comm.reduce([cnt[k] * scale for k in keys] + [cnt["rays"], cnt["exec_tests"]], "sum")
+    samples = w["nx"] * w["ny"] * w["spp"]
+    out = dict(elapsed=mx[0], kernel_ms=mx[1], samples=samples, steps=steps, nx=w["nx"], ny=w["ny"], spp=w["spp"],
+               value=samples * steps / mx[0] / 1e6, ms_per_step=mx[0] / steps * 1e3,
+               counters={k: sm[i] for i, k in enumerate(keys)}, counted_spp=cnt["spp"],
+               exec_tests_per_ray=(sm[-1] / sm[-2]) if sm[-2] else None, image=image)
+    return out
+
+
+def sphere_roofline(job, world, traffic=None):
+    """fp32 VALU roofline of the sphere kernel, per launch on one GPU."""
+    c = job["counters"]
+    rays = c["rays"] / world
+    flops = rays * (FLOPS_PER_TEST * N_SPHERES + FLOPS_PER_RAY)
+    achieved = flops / (job["kernel_ms"] * 1e-3) / 1e12
+    ex_flops = (FLOPS_PER_TEST * c["exec_tests"] + FLOPS_PER_BOX * c["box_tests"] + FLOPS_PER_RAY * c["rays"]) / world
+    ex = ex_flops / (job["kernel_ms"] * 1e-3) / 1e12
+    r = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+         "frac_definition": "ALGORITHMIC flops of the reference's brute-force scan (SURVEY.md §8d: rays x (18 x 488 + 80), rays counted on the "
+                            "GPU, bit-equal to the oracle's count) / kernel time / peak: an EFFECTIVE rate, not hardware utilisation",
+         "effective_frac": achieved / PEAK_FP32_VALU_TFLOPS,
+         "executed": {"tflops": ex, "frac": ex / PEAK_FP32_VALU_TFLOPS,
+                      "definition": "flops the kernel actually executes: 18 x executed sphere tests + 20 x group/node box tests + 80 x rays "
+                                    "(device counters) / kernel time; the exact culling executes exec_tests_per_ray of the 488 tests per ray",
+                      "exec_tests_per_ray": job["exec_tests_per_ray"],
+                      "box_tests_per_ray": (c["box_tests"] / c["rays"]) if c["rays"] else None},
+         "kernel": "k_render_spheres_queue", "kernel_ms_avg": job["kernel_ms"], "flops_per_launch": flops,
+         "algorithmic_hbm_bytes": job["nx"] * job["ny"] * 12,
+         "note": "one frame = one 'launch': with the reference RNG stream the persistent kernel is dispatched twice per frame (first 2 samples, then "
+                 "the cost-ordered rest) and kernel_ms_avg is the HIP-event time over both. fp32 VALU bound: no GEMM shape, no MFMA (157.3 TFLOP/s "
+                 "is also the dense fp32 MFMA peak of MI355X)"}
+    r.update(traffic or {"traffic": None})
+    return r
+
+
+def mesh_roofline(job, world, traffic=None):
+    """BVH-path roofline: gather bytes out of L2, 48 B per internal-node visit (the child pair),
+    64 B per triangle test, 64 B closest-hit refetch per ray; bound = the L2-served gather rate of the guide."""
+    c = job["counters"]
+    by = (48.0 * c["node_visits"] + 64.0 * c["prim_tests"] + 64.0 * c["rays"]) / world
+    fl = (30.0 * c["node_visits"] + 51.0 * c["prim_tests"] + 150.0 * c["rays"]) / world
+    achieved = by / (job["kernel_ms"] * 1e-3) / 1e12
+    r = {"bound": "l2-gather", "achieved": achieved, "peak": PEAK_L2_GATHER_TBPS, "unit": "TB/s", "frac": achieved / PEAK_L2_GATHER_TBPS,
+         "bytes_per_launch": by, "flops_per_launch": fl, "valu_tflops": fl / (job["kernel_ms"] * 1e-3) / 1e12,
+         "kernel": "k_render_mesh_queue", "kernel_ms_avg": job["kernel_ms"],
+         "per_sample": {k: c[k] / job["samples"] for k in ("rays", "shadow_rays", "node_visits", "prim_tests")},
+         "note": "algorithmic gather bytes = 48 x node visits + 64 x triangle tests + 64 x rays (device counters, equal to the oracle's) / kernel time; "
+                 "peak = chip-wide L2-served row-gather rate (MI355X_MICROARCH.md, 'Indexed rows'); the 3 MB working set never leaves L2"}
+    r.update(traffic or {"traffic": None})
+    return r
+
+
+# ------------------------------------------------------------------------------------------------------
+# HBM-side traffic: measured by tools/measure_traffic.py (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate passes
+# around tools/one_frame.py) and committed as profiles/traffic.json TOGETHER with the hash of the kernel sources
+# it was taken on; reported only while the sources still hash to that value (a changed kernel -> traffic null).
+# ------------------------------------------------------------------------------------------------------
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cuda-raytracing-optimized_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(config, algorithmic_bytes):
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return {"traffic": None, "traffic_source": "profiles/traffic.json absent"}
+    t = json.load(open(p))
+    if t.get("kernel_source_hash") != kernel_source_hash():
+        return {"traffic": None, "traffic_source": "profiles/traffic.json was taken on other kernel sources (hash mismatch): not reported"}
+    e = t.get(config)
+    if not e:
+        return {"traffic": None, "traffic_source": f"profiles/traffic.json has no entry for {config}"}
+    return {"traffic": e["bytes_per_frame"], "traffic_unit": "bytes/frame", "traffic_over_algorithmic": e["bytes_per_frame"] / algorithmic_bytes,
+            "traffic_source": f"committed_profile: profiles/traffic.json ({e.get('how', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2')}), "
+                              f"kernel sources {t['kernel_source_hash']}"}
+
+
+def cpu_baseline(w):
     """The reference's own header-only code as a single-threaded host loop (oracle/_ref), or our C
     restatement of it when the shim is absent, timed on a bounded sample of the SAME workload:
-    the full 1200x800 frame, first CPU_SPP samples of every pixel stream."""
+    the full frame, first CPU_SPP samples of every pixel stream."""
+    import cuda_raytracing_optimized_amd as rt
     from oracle import oracle as O
+    nx, ny = w["nx"], w["ny"]
     cpu_spp = int(os.environ.get("RT_BENCH_CPU_SPP", "8"))       # ~13 s of single-threaded CPU work
     sp, mt, cam = rt.scene_random_spheres(nx, ny)
     opt = O.default_options(True)
     t0 = time.perf_counter()
     if O.have_ref():
-        O.ref_render_spheres(sp, mt, cam, opt, nx, ny, cpu_spp, MAX_DEPTH)
+        O.ref_render_spheres(sp, mt, cam, opt, nx, ny, cpu_spp, w["depth"])
         kind = "reference"
     else:
-        O.render(O.sphere_scene(sp, mt), cam, opt, nx, ny, cpu_spp, MAX_DEPTH)
+        O.render(O.sphere_scene(sp, mt), cam, opt, nx, ny, cpu_spp, w["depth"])
         kind = "port"
     dt = time.perf_counter() - t0
     samples = nx * ny * cpu_spp
     return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": kind,
             "sample": f"{nx}x{ny} full frame, first {cpu_spp} spp of every pixel stream "
-                      f"({samples / 1e6:.2f} M of the {nx * ny * SPP / 1e6:.0f} M samples), {dt:.1f} s single-threaded",
+                      f"({samples / 1e6:.2f} M of the {nx * ny * w['spp'] / 1e6:.0f} M samples), {dt:.1f} s single-threaded",
             "host_cpus": os.cpu_count()}
+
+
+def brief(job, extra=None):
+    d = {"value": job["value"], "unit": "Msamples/s", "ms_per_step": job["ms_per_step"], "frame_ms_kernel": job["kernel_ms"],
+         "steps": job["steps"], "rays_per_sample": job["counters"]["rays"] / job["samples"]}
+    d.update(extra or {})
+    return d
 
 
 def main():
@@ -88,11 +312,10 @@ def main():
                     help="reference = the reference's per-pixel xorshift stream (the contract workload); counter = per-sample "
                          "stream, samples split over lanes (a different, equally valid estimate of the same image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spp", type=int, default=SPP, help="experiments only; the contract workload is 100")
-    ap.add_argument("--max-depth", type=int, default=MAX_DEPTH, help="experiments only; the contract workload is 50")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--spp", type=int, default=0, help="experiments only: overrides the headline workload's spp")
+    ap.add_argument("--max-depth", type=int, default=0, help="experiments only: overrides the headline workload's maxDepth")
     args = ap.parse_args()
-    globals()["SPP"] = args.spp
-    globals()["MAX_DEPTH"] = args.max_depth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,113 +331,94 @@ def main():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
     # One rank per GPU.  (Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_BACKEND=gloo maps the ranks onto the
     # GPUs that exist, round robin, and does the barrier / max over gloo; the driver's runs use nccl = RCCL.)
-    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    backend_name = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend_name == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
+    comm = LocalComm()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if backend_name == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend_name)
+        comm = DistComm(dist, "cuda" if backend_name == "nccl" else "cpu")
 
-    import cuda_raytracing_optimized_amd as rt
-    from cuda_raytracing_optimized_amd import multigpu
+    hip = HipBackend(args.fp, args.rng, args.variant)
+    tag = f"bench_{os.environ.get('MASTER_PORT', '0')}"
+    mode = f"{args.rng} RNG stream, fp {args.fp}"
+    default_mode = args.rng == "reference" and args.fp == "parity" and args.variant == 0
 
-    nx, ny = multigpu.image_size(world)
-    sp, mt, cam = rt.scene_random_spheres(nx, ny)
-    fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, MAX_DEPTH)
-    opt = rt.getDefaultRenderOptions(True)
-    fp = rt.RT_FP_FAST if args.fp == "fast" else rt.RT_FP_PARITY
-    rng_mode = rt.RT_RNG_COUNTER if args.rng == "counter" else rt.RT_RNG_REFERENCE_STREAM
-    rt.setRenderOptions(opt, fp=fp, rng=rng_mode, variant=args.variant, part_rank=rank, part_world=world, stripe_rows=8)
+    def with_overrides(w):
+        w = dict(w)
+        if args.spp:
+            w["spp"] = args.spp
+        if args.max_depth:
+            w["depth"] = args.max_depth
+        return w
 
-    # host gather target: one framebuffer shared by all ranks of the node
-    shared = None
-    if world > 1:
-        shared = multigpu.SharedFramebuffer(f"bench_{os.environ.get('MASTER_PORT', '0')}", nx, ny, rank, dist.barrier)
-        rt.setExternalFramebuffer(shared.array)     # every rank's D2H stripe copies land in the one shared framebuffer
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def step():
-        rt.runRenderer(SPP, 8, 8)                # blocking: kernel + D2H (hipMemcpy2DAsync) of this rank's stripes = the host gather
-
-    # one counted run (untimed): rays per frame for the algorithmic flop count
-    rt.setRenderOptions(opt, counters=1)
-    step()
-    _st = rt.getRenderStats()
-    rays_local = _st.rays
-    exec_tests_local = _st.exec_tests
-    rt.setRenderOptions(opt, counters=0)
-    for _ in range(args.warmup):
-        step()
-
-    sync()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(rt.getRenderStats().kernel_ms)
-    sync()
-    elapsed = time.perf_counter() - t0
-
-    stats = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(rays_local)], dtype=torch.float64,
-                         device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        tmax = stats.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, kern_ms_max, rays_total = tmax[0].item(), tmax[1].item(), tsum[2].item()
+    others = {}
+    if world == 1:
+        w = with_overrides(WORKLOADS["C2"])
+        job = run_job(hip, comm, w, args.steps, args.warmup, tag)
+        metric = "Msamples/s (pixels x spp / s), random-spheres 1200x800x100spp"
+        scaling = "weak"                     # one GPU: nothing is partitioned (the N > 1 lines say "strong")
+        partition = "single GPU"
+        roof = sphere_roofline(job, 1, committed_traffic("C2", w["nx"] * w["ny"] * 12) if default_mode else None)
+        if not args.no_other_configs:
+            # C3: the same frame at 1000 spp
+            j3 = run_job(hip, comm, WORKLOADS["C3"], 2, 1, tag, count_spp=8, warmup_spp=16)
+            others["C3"] = brief(j3, {"workload": WORKLOADS["C3"]["name"] + ", " + mode,
+                                      "roofline": {k: v for k, v in sphere_roofline(j3, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "executed", "traffic")}})
+            # C4: triangle mesh + BVH through the reference's own entry point
+            j4 = run_job(HipBackend(args.fp, "reference", 0), comm, WORKLOADS["C4"], 2, 1, tag, count_spp=4, warmup_spp=16)
+            w4 = WORKLOADS["C4"]
+            others["C4"] = brief(j4, {"workload": w4["name"] + f", fp {args.fp}",
+                                      "roofline": mesh_roofline(j4, 1, committed_traffic("C4", w4["nx"] * w4["ny"] * 12) if args.fp == "parity" else None)})
+            # C5's workload on this one GPU (the denominator of the N > 1 strong-scaling lines)
+            j5 = run_job(hip, comm, WORKLOADS["C5"], 1, 1, tag, count_spp=4, warmup_spp=16)
+            others["C5_one_gpu"] = brief(j5, {"workload": WORKLOADS["C5"]["name"] + ", " + mode + "; the whole frame on ONE GPU",
+                                              "roofline": {k: v for k, v in sphere_roofline(j5, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "executed", "traffic")}})
     else:
-        elapsed, kern_ms_max, rays_total = stats[0].item(), stats[1].item(), stats[2].item()
+        w = with_overrides(WORKLOADS["C5"])
+        job = run_job(hip, comm, w, args.steps, args.warmup, tag, count_spp=4, warmup_spp=16)
+        metric = f"Msamples/s (pixels x spp / s), random-spheres 3840x2160x{w['spp']}spp split over {world} GPUs (BASELINE.json configs[4])"
+        scaling = "strong"
+        partition = f"{world} x interleaved 8-row stripes of the fixed 3840x2160 image, host gather into one shared pinned framebuffer, no collective"
+        roof = sphere_roofline(job, world)
+        if not args.no_other_configs:
+            # the north star's "1200x800x100 at 1/2/4/8 GPUs": same partitioned job on C2
+            j2 = run_job(hip, comm, WORKLOADS["C2"], max(args.steps, 5), 1, tag + "_c2")
+            others["C2_partitioned"] = brief(j2, {"workload": WORKLOADS["C2"]["name"] + ", " + mode + f"; the fixed 1200x800 image over {world} GPUs",
+                                                  "note": "strong scaling of a 16 ms frame: per-GPU kernel time is a few ms, the rest is launch, D2H and barrier"})
+            # the same C5 frame on rank 0's GPU alone: this line's own strong-scaling denominator
+            solo = None
+            if rank == 0:
+                js = run_job(hip, LocalComm(), w, 1, 1, tag + "_solo", count_spp=4, warmup_spp=16)
+                solo = brief(js, {"workload": w["name"] + "; whole frame on rank 0's GPU alone while the other ranks wait"})
+            comm.barrier()
+            if solo:
+                others["single_gpu_same_workload"] = solo
 
     if rank == 0:
-        total_samples = nx * ny * SPP
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_samples * args.steps / elapsed / 1e6
-        # roofline of the dominant (only) kernel, per launch on one GPU
-        rays_per_gpu = rays_total / world
-        flops_per_launch = rays_per_gpu * (FLOPS_PER_TEST * N_SPHERES + FLOPS_PER_RAY)
-        achieved = flops_per_launch / (kern_ms_max * 1e-3) / 1e12
-        traffic, traffic_src = measured_hbm_traffic() if (world == 1 and args.rng == "reference" and args.fp == "parity") else (None, None)
         out = {
-            "metric": "Msamples/s (pixels x spp / s), random-spheres 1200x800x100spp",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": metric,
+            "value": job["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": job["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"random-spheres (488 spheres, LCG seed 0) {nx}x{ny} {SPP}spp maxDepth {MAX_DEPTH}, "
-                                   f"gradient sky, {args.rng} RNG stream, fp {args.fp}",
-                       "image": [nx, ny], "spp": SPP, "max_depth": MAX_DEPTH, "spheres": N_SPHERES,
-                       "partition": f"{world} x interleaved 8-row stripes, host gather" if world > 1 else "single GPU",
-                       "fp_mode": args.fp, "rng": args.rng, "kernel_variant": args.variant},
-            "frame_ms_kernel": kern_ms_max,
-            "rays_per_sample": rays_total / total_samples,
-            "executed_sphere_tests_per_ray_rank0": (exec_tests_local / rays_local) if rays_local else None,
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/frame",
-                         "traffic_source": traffic_src,
-                         "kernel": "k_render_spheres_queue", "kernel_ms_avg": kern_ms_max,
-                         "flops_per_launch": flops_per_launch,
-                         "note": "one frame = one 'launch' here: with the reference RNG stream the persistent kernel is dispatched "
-                                 "twice per frame (first 2 samples, then the cost-ordered rest) and kernel_ms_avg / traffic are "
-                                 "the sums over both. fp32 VALU bound: no GEMM shape, no MFMA (157.3 TFLOP/s is also the dense fp32 MFMA peak of "
-                                 "MI355X, so frac is the same under either label); algorithmic HBM bytes = 11.5 MB framebuffer per frame. achieved = "
-                                 "algorithmic flops of the reference's brute-force scan, rays x (18 x 488 + 80) with rays counted "
-                                 "on the GPU (bit-equal to the oracle's count), / kernel time; the kernel's exact group culling "
-                                 "executes only executed_sphere_tests_per_ray of the 488 tests per ray"},
+            "config": {"workload": w["name"] + ", " + mode, "image": [w["nx"], w["ny"]], "spp": w["spp"], "max_depth": w["depth"],
+                       "spheres": N_SPHERES, "partition": partition, "fp_mode": args.fp, "rng": args.rng, "kernel_variant": args.variant},
+            "frame_ms_kernel": job["kernel_ms"],
+            "rays_per_sample": job["counters"]["rays"] / job["samples"],
+            "executed_sphere_tests_per_ray": job["exec_tests_per_ray"],
+            "roofline": roof,
         }
+        if others:
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rt, nx, ny)
+            out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
 
-    rt.cleanupRenderer()
     if world > 1:
-        shared.close(dist.barrier)
         dist.destroy_process_group()
 
 

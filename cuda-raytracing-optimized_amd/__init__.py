@@ -99,7 +99,18 @@ class render_options(C.Structure):
 class render_stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("samples", C.c_int64),
                 ("num_launches", C.c_int32), ("vgprs", C.c_int32), ("rays", C.c_uint64),
-                ("prim_tests", C.c_uint64), ("node_visits", C.c_uint64), ("exec_tests", C.c_uint64)]
+                ("prim_tests", C.c_uint64), ("node_visits", C.c_uint64), ("exec_tests", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("box_tests", C.c_uint64), ("ref_stats", C.c_uint64 * 18)]
+
+
+# indices into render_stats.ref_stats: the reference's STATS counters, /root/reference/kernels.cu:47-67
+(RT_STAT_PRIMARY, RT_STAT_PRIMARY_HIT_MESH, RT_STAT_PRIMARY_NOHITS, RT_STAT_PRIMARY_BBOX_NOHITS, RT_STAT_SECONDARY,
+ RT_STAT_SECONDARY_MESH, RT_STAT_SECONDARY_NOHIT, RT_STAT_SECONDARY_MESH_NOHIT, RT_STAT_SECONDARY_BBOX_NOHIT, RT_STAT_SHADOWS,
+ RT_STAT_SHADOWS_BBOX_NOHITS, RT_STAT_SHADOWS_NOHITS, RT_STAT_LOW_POWER, RT_STAT_EXCEED_MAX_BOUNCE, RT_STAT_RUSSIAN_KILL,
+ RT_STAT_NAN, RT_STAT_NODES_BOTH, RT_STAT_NODES_SINGLE) = range(18)
+RT_STAT_NAMES = ["primary", "primary hit mesh", "primary nohit", "primary bb nohit", "secondary", "secondary mesh", "secondary no hit",
+                 "secondary mesh nohit", "secondary bb nohit", "shadows", "shadows bb nohit", "shadows nohit", "power < 0.01",
+                 "exceeded max bounce", "russian roulette", "NaNs", "both nodes hit", "single node hit"]
 
 
 _SIZES = {vec3: 12, camera: 88, sphere: 16, plane: 24, bbox: 24, triangle: 64, bvh_node: 24, material: 24,

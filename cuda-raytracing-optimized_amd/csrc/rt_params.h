@@ -30,6 +30,8 @@ struct RtCounters {             // device-side, optional
     unsigned long long node_visits;
     unsigned long long shadow_rays;
     unsigned long long exec_tests;   // sphere tests actually executed per lane in the lane-parallel scan (after group culling)
+    unsigned long long box_tests;    // sphere scenes: group / node box slab tests executed
+    unsigned long long ref_stats[RT_STAT_COUNT];   // the reference's STATS counters, kernels.cu:47-67
 };
 
 struct RtSphereParams {

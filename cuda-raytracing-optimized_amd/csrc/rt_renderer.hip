@@ -363,7 +363,7 @@ void cleanup_impl() {
 
 extern "C" {
 
-int rtApiVersion(void) { return 1000; }
+int rtApiVersion(void) { return 1001; }
 
 int rtDeviceCount(void) {
     int count = 0;
@@ -589,7 +589,8 @@ void runRenderer(int ns, int tx, int ty) {
             RtCounters h;
             HIP_CHECK(hipMemcpy(&h, d.d_counters, sizeof h, hipMemcpyDeviceToHost));
             st.rays += h.rays; st.prim_tests += h.prim_tests; st.node_visits += h.node_visits;
-            st.exec_tests += h.exec_tests;
+            st.exec_tests += h.exec_tests; st.shadow_rays += h.shadow_rays; st.box_tests += h.box_tests;
+            for (int q = 0; q < RT_STAT_COUNT; q++) st.ref_stats[q] += h.ref_stats[q];
         }
     }
     HIP_CHECK(hipSetDevice(current));

@@ -1,7 +1,7 @@
 """Multi-GPU plumbing for one node: the image is cut into interleaved row stripes, one process per GPU renders
 its stripes, and the stripes are gathered ON THE HOST into one framebuffer shared by the ranks (a memory-mapped
 file in /dev/shm) — no collective on the data path.  torch.distributed is used only for the
-barrier / max-over-ranks timing the bench contract asks for.
+barrier / max-over-ranks timing the bench contract asks for (bench.py run_job).
 
 Nothing here touches the GPU: the same code runs in the world-size-2 gloo tests on CPU."""
 import os
@@ -9,15 +9,6 @@ import os
 import numpy as np
 
 STRIPE_ROWS = 8
-
-
-def image_size(n_gpus, base=(1200, 800)):
-    """Weak-scaling workload: 3:2 image with ~base pixels PER GPU, both sides multiples of 8."""
-    if n_gpus == 1:
-        return base
-    nx = int(round(base[0] * n_gpus ** 0.5 / 8.0)) * 8
-    ny = int(round(nx * base[1] / base[0] / 8.0)) * 8
-    return nx, ny
 
 
 def stripe_rows(rank, world, ny, stripe=STRIPE_ROWS):
@@ -29,15 +20,20 @@ def stripe_rows(rank, world, ny, stripe=STRIPE_ROWS):
 
 
 class SharedFramebuffer:
-    """One (ny, nx, 3) float32 framebuffer visible to every rank of the node."""
+    """One (ny, nx, 3) float32 framebuffer visible to every rank of the node: a raw (header-less) file in /dev/shm,
+    so the mapping — which every rank page-locks with hipHostRegister (setExternalFramebuffer) — starts on a page."""
 
     def __init__(self, tag, nx, ny, rank, barrier):
-        self.path = f"/dev/shm/rt_fb_{tag}.npy"
+        self.path = f"/dev/shm/rt_fb_{tag}.raw"
         self.rank = rank
+        self.array = None
         if rank == 0:
-            np.lib.format.open_memmap(self.path, mode="w+", dtype=np.float32, shape=(ny, nx, 3)).flush()
+            m = np.memmap(self.path, dtype=np.float32, mode="w+", shape=(ny, nx, 3))
+            m.flush()
+            del m
         barrier()
-        self.array = np.load(self.path, mmap_mode="r+")
+        self.array = np.memmap(self.path, dtype=np.float32, mode="r+", shape=(ny, nx, 3))
+        assert self.array.ctypes.data % 4096 == 0
 
     def gather(self, fb, rank, world, stripe=STRIPE_ROWS):
         """Host-side gather of this rank's stripes: one contiguous memcpy per stripe into the shared mapping.
@@ -48,10 +44,12 @@ class SharedFramebuffer:
             self.array[k * stripe:k * stripe + stripe] = fb[k * stripe:k * stripe + stripe]
 
     def close(self, barrier):
-        barrier()
-        del self.array
-        if self.rank == 0:
-            try:
-                os.unlink(self.path)
-            except OSError:
-                pass
+        try:
+            barrier()
+        finally:
+            self.array = None
+            if self.rank == 0:
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass

@@ -176,6 +176,14 @@ typedef struct rt_render_options {
                                are split over lanes; partial sums are added in chunk order). 0 = default (4).    */
 } rt_render_options;
 
+/* The reference's `#ifdef STATS` ray statistics (kernels.cu:47-67: NUM_RAYS_* / NUM_NODES_*), same order.  Filled when
+ * rt_render_options.counters = 1.  PLANE-related distinctions do not arise (the floor's call site is commented out at HEAD,
+ * kernels.cu:341-345), so SECONDARY_MESH = SECONDARY and SECONDARY_NOHIT = 0 exactly as in a STATS build of HEAD. */
+enum { RT_STAT_PRIMARY = 0, RT_STAT_PRIMARY_HIT_MESH, RT_STAT_PRIMARY_NOHITS, RT_STAT_PRIMARY_BBOX_NOHITS,
+       RT_STAT_SECONDARY, RT_STAT_SECONDARY_MESH, RT_STAT_SECONDARY_NOHIT, RT_STAT_SECONDARY_MESH_NOHIT, RT_STAT_SECONDARY_BBOX_NOHIT,
+       RT_STAT_SHADOWS, RT_STAT_SHADOWS_BBOX_NOHITS, RT_STAT_SHADOWS_NOHITS, RT_STAT_LOW_POWER, RT_STAT_EXCEED_MAX_BOUNCE,
+       RT_STAT_RUSSIAN_KILL, RT_STAT_NAN, RT_STAT_NODES_BOTH, RT_STAT_NODES_SINGLE, RT_STAT_COUNT };
+
 typedef struct rt_render_stats {
     double  kernel_ms;      /* HIP-event time of the render kernel(s) of the last runRenderer, max over devices */
     double  total_ms;       /* wall time of the last runRenderer incl. gather                                   */
@@ -186,6 +194,10 @@ typedef struct rt_render_stats {
     uint64_t prim_tests;    /* sphere or triangle tests                                                         */
     uint64_t node_visits;   /* BVH internal-node visits                                                         */
     uint64_t exec_tests;    /* sphere tests actually executed per lane after group culling (sphere scenes)     */
+    /* --- appended in API version 1001 (older callers that pass the shorter struct must not call getRenderStats of 1001+) --- */
+    uint64_t shadow_rays;   /* shadow rays traced (mesh scenes with NEE)                                        */
+    uint64_t box_tests;     /* sphere scenes: group / node bounding-box slab tests executed by the culling      */
+    uint64_t ref_stats[RT_STAT_COUNT];  /* the reference's STATS counters (kernels.cu:47-67), same indices, same meaning   */
 } rt_render_stats;
 
 #endif /* RT_TYPES_H */

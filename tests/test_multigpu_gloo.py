@@ -1,13 +1,14 @@
-"""CPU, world_size 2 (gloo): the N>1 path of bench.py — stripe partition, host-side gather into the framebuffer
-shared by the ranks, barrier + max-over-ranks timing.  The stripes are rendered by the CPU oracle here (test
-infrastructure standing in for the GPU, which this container does not have); the assembled image must equal the
-single-process image bit for bit, because pixel seeds depend on the global pixel id only."""
+"""CPU, world_size 2 and 3 (gloo): the N>1 path of bench.py.  The workers call bench.run_job() — THE partitioned job
+of the benchmark: stripe partition, framebuffer shared by the ranks, barrier-bracketed timing, max / sum over ranks
+through bench.DistComm — with a backend that renders the rank's stripes with the CPU oracle (test infrastructure
+standing in for the GPU, which this container does not have; on the GPU box the backend is bench.HipBackend).
+The assembled image must equal the single-process image bit for bit, because pixel seeds depend on the global
+pixel id only, and the whole-job counters must equal the single-process counters."""
 import os
 import socket
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -22,58 +23,107 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nx, ny, ns, out_path):
+class OracleBackend:
+    """bench.HipBackend's interface on the CPU oracle: renders this rank's stripes, then gathers them on the host."""
+
+    def __init__(self):
+        import cuda_raytracing_optimized_amd as rt
+        from cuda_raytracing_optimized_amd import multigpu
+        from oracle import oracle as O
+        self.rt, self.O, self.multigpu = rt, O, multigpu
+
+    def open(self, w, rank, world, shared_fb):
+        assert w["kind"] == "spheres"
+        self.w, self.rank, self.world, self.shared = w, rank, world, shared_fb
+        self.sp, self.mt, self.cam = self.rt.scene_random_spheres(w["nx"], w["ny"])
+        self.fb = np.zeros((w["ny"], w["nx"], 3), np.float32)
+
+    def _render(self, spp, counters=False):
+        w, O = self.w, self.O
+        sc = O.sphere_scene(self.sp, self.mt)
+        opt = O.default_options(True)
+        rays = tests = 0
+        for k in range(self.rank, (w["ny"] + 7) // 8, self.world):              # this rank's stripes only
+            _, c = O.render(sc, self.cam, opt, w["nx"], w["ny"], spp, w["depth"],
+                            region=(0, k * 8, w["nx"], min(w["ny"], k * 8 + 8)), fb=self.fb, counters=counters)
+            if counters:
+                rays += c.rays; tests += c.prim_tests
+        if self.shared is not None:                                              # host gather: plain memcpy per stripe
+            for k in range(self.rank, (w["ny"] + 7) // 8, self.world):
+                self.shared[k * 8:k * 8 + 8] = self.fb[k * 8:k * 8 + 8]
+        return rays, tests
+
+    def step(self, spp=None):
+        self._render(spp or self.w["spp"])
+        return 1.0
+
+    def counted(self, spp):
+        rays, tests = self._render(spp, counters=True)
+        return dict(rays=rays, exec_tests=tests, node_visits=0, prim_tests=tests, box_tests=0, shadow_rays=0, spp=spp)
+
+    def device_sync(self):
+        pass
+
+    def image(self):
+        return self.fb.copy()
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, w, out_path):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import cuda_raytracing_optimized_amd as rt
-    from cuda_raytracing_optimized_amd import multigpu
-    from oracle import oracle as O
-    sp, mt, cam = rt.scene_random_spheres(nx, ny)
-    rows = multigpu.stripe_rows(rank, world, ny)
-    shared = multigpu.SharedFramebuffer(f"test_{port}", nx, ny, rank, dist.barrier)
-    fb = np.zeros((ny, nx, 3), np.float32)
-    sc = O.sphere_scene(sp, mt)
-    opt = O.default_options(True)
-    for k in range(rank, (ny + 7) // 8, world):                      # this rank's stripes only
-        O.render(sc, cam, opt, nx, ny, ns, 50, region=(0, k * 8, nx, min(ny, k * 8 + 8)), fb=fb)
-    shared.gather(fb, rank, world)
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
+    import bench
+    comm = bench.DistComm(dist, "cpu")
+    job = bench.run_job(OracleBackend(), comm, w, steps=2, warmup=1, tag=f"test_{port}", keep_image=True)
     if rank == 0:
-        np.save(out_path, np.array(shared.array))
-        assert t.item() == float(world)
-    shared.close(dist.barrier)
+        np.save(out_path, job["image"])
+        np.save(out_path + ".cnt.npy", np.array([job["counters"]["rays"], job["counters"]["prim_tests"], job["value"], job["elapsed"]]))
+    assert job["samples"] == w["nx"] * w["ny"] * w["spp"] and job["steps"] == 2
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,nx,ny", [(2, 64, 44), (3, 40, 64)])
-def test_stripes_gather_to_the_single_process_image(tmp_path, world, nx, ny):
-    import sys
-    sys.path.insert(0, ROOT)
-    import cuda_raytracing_optimized_amd as rt
-    from oracle import oracle as O
-    ns = 2
+def test_bench_run_job_partitions_and_gathers_the_single_process_image(tmp_path, world, nx, ny, rt, O):
+    w = dict(kind="spheres", nx=nx, ny=ny, spp=2, depth=50, name="test")
     out = str(tmp_path / "fb.npy")
-    mp.spawn(_worker, args=(world, _free_port(), nx, ny, ns, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, out), nprocs=world, join=True)
     got = np.load(out)
     sp, mt, cam = rt.scene_random_spheres(nx, ny)
-    ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, 2, 50, counters=True)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    rays, tests, value, elapsed = np.load(out + ".cnt.npy")
+    assert rays == cnt.rays and tests == cnt.prim_tests                           # SUM over ranks = the whole job
+    assert elapsed > 0 and abs(value - nx * ny * 2 * 2 / elapsed / 1e6) < 1e-9 * value
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_fb_test_")]   # the shared framebuffer is unlinked
+
+
+def test_run_job_single_rank_needs_no_shared_framebuffer(rt, O):
+    import bench
+    w = dict(kind="spheres", nx=32, ny=24, spp=1, depth=50, name="test")
+    job = bench.run_job(OracleBackend(), bench.LocalComm(), w, steps=1, warmup=0, keep_image=True)
+    sp, mt, cam = rt.scene_random_spheres(32, 24)
+    ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), 32, 24, 1, 50)
+    assert np.array_equal(job["image"].view(np.uint32), ref.view(np.uint32))
 
 
 def test_partition_covers_every_row_once():
-    import sys
-    sys.path.insert(0, ROOT)
     from cuda_raytracing_optimized_amd import multigpu
-    for ny in (1, 7, 8, 9, 800, 1128, 2264, 803):
+    for ny in (1, 7, 8, 9, 800, 1128, 2160, 2264, 803):
         for world in (1, 2, 3, 4, 8):
             rows = np.concatenate([multigpu.stripe_rows(r, world, ny) for r in range(world)])
             assert sorted(rows.tolist()) == list(range(ny)), (ny, world)
-    assert multigpu.image_size(1) == (1200, 800) and multigpu.image_size(4) == (2400, 1600)
-    for n in (2, 8):
-        nx, ny = multigpu.image_size(n)
-        assert nx % 8 == 0 and ny % 8 == 0 and abs(nx * ny / (960000 * n) - 1) < 0.01
+
+
+def test_bench_workloads_are_the_baseline_configs():
+    import json
+    import bench
+    cfg = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    assert "1200" in cfg[1] and "100spp" in cfg[1] and (bench.WORKLOADS["C2"]["nx"], bench.WORKLOADS["C2"]["ny"], bench.WORKLOADS["C2"]["spp"]) == (1200, 800, 100)
+    assert "1000spp" in cfg[2] and bench.WORKLOADS["C3"]["spp"] == 1000
+    assert "1920" in cfg[3] and (bench.WORKLOADS["C4"]["nx"], bench.WORKLOADS["C4"]["ny"], bench.WORKLOADS["C4"]["spp"]) == (1920, 1080, 256)
+    assert "3840" in cfg[4] and (bench.WORKLOADS["C5"]["nx"], bench.WORKLOADS["C5"]["ny"], bench.WORKLOADS["C5"]["spp"]) == (3840, 2160, 4096)
