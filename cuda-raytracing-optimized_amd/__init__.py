@@ -93,7 +93,7 @@ class render_options(C.Structure):
                 ("rng", C.c_int32), ("fp", C.c_int32), ("light", sphere), ("lightColor", vec3),
                 ("stripe_rows", C.c_int32), ("num_devices", C.c_int32), ("devices", C.c_int32 * RT_MAX_DEVICES),
                 ("part_rank", C.c_int32), ("part_world", C.c_int32), ("variant", C.c_int32), ("counters", C.c_int32),
-                ("samples_per_item", C.c_int32)]
+                ("samples_per_item", C.c_int32), ("floor", C.c_int32)]
 
 
 class render_stats(C.Structure):

@@ -174,6 +174,10 @@ typedef struct rt_render_options {
     int32_t counters;       /* 1 = count rays / primitive tests / node visits (getRenderStats) */
     int32_t samples_per_item; /* RT_RNG_COUNTER only: samples per work item (a pixel's samples are independent there and
                                are split over lanes; partial sums are added in chunk order). 0 = default (4).    */
+    /* --- appended in API version 1001 --- */
+    int32_t floor;          /* mesh scenes: 1 = rays that miss the mesh are tested against kernel_scene.floor (planeHit, intersections.h:43-52)
+                               and scatter with floor_diffuse_scatter (scene_materials.h:30-33): the call site the reference keeps
+                               commented out at HEAD (kernels.cu:341-345, 481-482).  Default 0 = HEAD behaviour.                 */
 } rt_render_options;
 
 /* The reference's `#ifdef STATS` ray statistics (kernels.cu:47-67: NUM_RAYS_* / NUM_NODES_*), same order.  Filled when

@@ -20,12 +20,13 @@ class orc_scene(C.Structure):
     _fields_ = [("spheres", C.c_void_p), ("sphere_materials", C.c_void_p), ("num_spheres", C.c_int32),
                 ("tris", C.c_void_p), ("num_tris", C.c_int32), ("bvh", C.c_void_p), ("num_bvh_nodes", C.c_int32),
                 ("bounds", C.c_float * 6), ("nppl", C.c_int32), ("materials", C.c_void_p), ("num_materials", C.c_int32),
-                ("textures", C.c_void_p), ("num_textures", C.c_int32)]
+                ("textures", C.c_void_p), ("num_textures", C.c_int32), ("floor", C.c_float * 6)]
 
 
 class orc_counters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("prim_tests", C.c_uint64),
-                ("node_visits", C.c_uint64), ("hits", C.c_uint64), ("rng_draws", C.c_uint64)]
+                ("node_visits", C.c_uint64), ("hits", C.c_uint64), ("rng_draws", C.c_uint64),
+                ("ref_stats", C.c_uint64 * 18)]       # the reference's STATS counters (kernels.cu:47-67), indices rt.RT_STAT_*
 
 
 class orc_scatter(C.Structure):
@@ -86,6 +87,8 @@ def load_oracle():
         lib.orc_hit_bvh.argtypes = [C.POINTER(orc_scene), _fp, _fp, C.c_float, C.c_float, C.c_int, _u32p, _fp, _fp,
                                     C.POINTER(orc_counters)]
         lib.orc_hit_bvh.restype = C.c_float
+        lib.orc_generate_shadow_ray.argtypes = [C.POINTER(rt.render_options), _fp, _fp, _fp, _u32p, _fp]
+        lib.orc_generate_shadow_ray.restype = C.c_int
         lib.orc_rmse.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.orc_rmse.restype = C.c_double
         _oracle = lib
@@ -114,6 +117,13 @@ def load_ref():
                                            C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(orc_counters)]
         lib.ref_render_spheres.restype = None
+        lib.ref_generate_shadow_ray.argtypes = [C.POINTER(rt.render_options), _fp, _fp, _fp, _u32p, _fp]
+        lib.ref_generate_shadow_ray.restype = C.c_int
+        lib.ref_render_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _fp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(rt.camera), C.POINTER(rt.render_options),
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.POINTER(orc_counters)]
+        lib.ref_render_mesh.restype = None
         _ref = lib
     return _ref
 
@@ -156,7 +166,8 @@ def sphere_scene(spheres, materials):
     return sc
 
 
-def mesh_scene(host_mesh, materials, textures=()):
+def mesh_scene(host_mesh, materials, textures=(), floor=None):
+    """floor = (norm xyz, point xyz) of kernel_scene.floor (only read with rt_render_options.floor = 1)."""
     rt = _pkg()
     materials = np.ascontiguousarray(materials, dtype=rt.material_dtype)
     sc = orc_scene()
@@ -180,6 +191,9 @@ def mesh_scene(host_mesh, materials, textures=()):
         tex_arr[k].height, tex_arr[k].width = t.shape[0], t.shape[1]
     sc.textures = C.cast(tex_arr, C.c_void_p) if textures else None
     sc.num_textures = len(textures)
+    if floor is not None:
+        for a in range(6):
+            sc.floor[a] = float(floor[a])
     sc._keep = keep
     return sc
 
@@ -212,3 +226,30 @@ def ref_render_spheres(spheres, materials, cam, opt, nx, ny, ns, max_depth, regi
                            1 if opt.rng == rt.RT_RNG_COUNTER else 0,
                            nx, ny, ns, max_depth, x0, y0, x1, y1, fb.ctypes.data, C.byref(cnt) if counters else None)
     return fb, cnt
+
+
+def ref_render_mesh(scene, cam, opt, nx, ny, ns, max_depth, region=None, counters=False, fb=None):
+    """The reference-arithmetic twin of the MESH path (oracle/ref_driver.cpp ref_render_mesh) on an orc_scene from mesh_scene().
+    Same return as render()."""
+    lib = load_ref()
+    if fb is None:
+        fb = np.zeros((ny, nx, 3), np.float32)
+    x0, y0, x1, y1 = region if region else (0, 0, nx, ny)
+    cnt = orc_counters() if counters else None
+    lib.ref_render_mesh(scene.tris, scene.bvh, scene.num_bvh_nodes, scene.bounds, scene.nppl,
+                        C.addressof(scene) + orc_scene.floor.offset, scene.materials, scene.textures,
+                        C.byref(cam), C.byref(opt), nx, ny, ns, max_depth, x0, y0, x1, y1,
+                        fb.ctypes.data, C.byref(cnt) if counters else None)
+    return fb, cnt
+
+
+def generate_shadow_ray(opt, origin, attenuation, normal, rng, which="orc"):
+    """generateShadowRay (kernels.cu:363-393) on one input by the oracle ("orc") or the reference-header twin ("ref").
+    Returns (generated, shadowDir[3], lightContribution[3], lightDist, cosAMax, draws, rng_after)."""
+    lib = load_oracle() if which == "orc" else load_ref()
+    fn = lib.orc_generate_shadow_ray if which == "orc" else lib.ref_generate_shadow_ray
+    st = C.c_uint32(int(rng))
+    out = (C.c_float * 9)()
+    ok = fn(C.byref(opt), f3(origin), f3(attenuation), f3(normal), C.byref(st), out)
+    o = np.array(out[:], np.float32)
+    return ok, o[0:3], o[3:6], o[6], o[7], int(o[8]), st.value

@@ -16,6 +16,14 @@
  * Exports:
  *   ref_*            one wrapper per reference function on the hot path (same argument meaning
  *                    as the orc_* function of the same name in rt_oracle.h)
+ *   ref_render_mesh      the MESH path's twin: render() / color() / hit() / hitMesh() / hitBvh() / generateShadowRay()
+ *                    of kernels.cu:154-224,296-569 as a host loop whose control flow is transcribed from there (kernels.cu
+ *                    itself cannot be compiled here: <<<>>>, tex1Dfetch, threadIdx) and whose EVERY arithmetic step is a
+ *                    call into the reference's own headers: vec3 operators, ray, hit_bbox, hit_bbox_dist, triangleHit,
+ *                    sphereHit, planeHit, material_scatter / the preset scatters, rnd, wang_hash, get_ray, cosf/sinf and
+ *                    the double M_PI expressions as written.  Pins oracle/rt_oracle.c's mesh path (tests/test_oracle_vs_ref.py).
+ *   ref_generate_shadow_ray   the same generateShadowRay twin on tabulated inputs (pins orc_generate_shadow_ray and,
+ *                    through it, the device probe rtProbeShadowRay)
  *   ref_render_spheres   a single-threaded host loop over pixels and samples for SPHERE scenes
  *                    whose every arithmetic step is a call into the reference headers
  *                    (get_ray, sphereHit, material_scatter, rnd, wang_hash, vec3 operators).
@@ -240,6 +248,328 @@ void ref_render_spheres(const rt_sphere* spheres_, const rt_material* mats_, int
                 }
                 col += p.color;
                 if (cnt) cnt->samples++;
+            }
+            fb[pixelId] = col / float(ns);
+        }
+}
+
+
+} /* extern "C" */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Mesh path twin.  What stands in for kernels.cu's RenderContext (kernels.cu:69-143); the BVH is the plain
+ * bvh_node array of the non-texture branch (kernels.cu:174-176: same floats as the 3-texel fetch of :166-173).
+ * ------------------------------------------------------------------------------------------------------------ */
+namespace {
+
+struct MeshCtx {
+    const triangle* tris;
+    const bvh_node* bvh;
+    uint32_t firstLeafIdx;              /* kernels.cu:614 */
+    uint32_t numPrimitivesPerLeaf;
+    bbox bounds;
+    plane floor;
+    int maxDepth;
+    sphere light;
+    vec3 lightColor;
+    const material* materials;
+    const rt_stexture* textures;
+    /* the reference's compile-time switches, as run-time values */
+    bool shadow, russian_roulette, gradient_sky, use_floor;
+    float epsilon;                      /* kernels.cu:19 */
+    orc_counters* cnt;
+    void stat(int k) const { if (cnt) cnt->ref_stats[k]++; }
+};
+
+enum { T_NONE, T_TRIMESH, T_PLANE, T_LIGHT };   /* kernels.cu:40-45 */
+
+void twin_pop(unsigned int& bitStack, int& idx) {                 /* kernels.cu:148-152 */
+    const int m = __builtin_ffsll(bitStack) - 1;
+    bitStack = (bitStack >> m) ^ 1;
+    idx = (idx >> m) ^ 1;
+}
+
+float twin_hit_bvh(const ray& r, const MeshCtx& cx, float t_min, float t_max, tri_hit& rec, bool isShadow) {   /* kernels.cu:154-224 */
+    int idx = 1;
+    float closest = t_max;
+    unsigned int bitStack = 1;
+    while (idx) {
+        if (idx < (int)cx.firstLeafIdx) {
+            const int idx2 = idx << 1;
+            bvh_node left = cx.bvh[idx2];
+            bvh_node right = cx.bvh[idx2 + 1];
+            if (cx.cnt) cx.cnt->node_visits++;
+            const float leftHit = hit_bbox_dist(left.min(), left.max(), r, closest);
+            const bool traverseLeft = leftHit < closest;
+            const float rightHit = hit_bbox_dist(right.min(), right.max(), r, closest);
+            const bool traverseRight = rightHit < closest;
+            const bool swap = rightHit < leftHit;
+            if (traverseLeft && traverseRight) {
+                cx.stat(RT_STAT_NODES_BOTH);
+                idx = idx2 + (swap ? 1 : 0);
+                bitStack = (bitStack << 1) + 1;
+            } else if (traverseLeft || traverseRight) {
+                cx.stat(RT_STAT_NODES_SINGLE);
+                idx = idx2 + (swap ? 1 : 0);
+                bitStack = bitStack << 1;
+            } else {
+                twin_pop(bitStack, idx);
+            }
+        } else {
+            const int first = (idx - cx.firstLeafIdx) * cx.numPrimitivesPerLeaf;
+            for (unsigned i = 0; i < cx.numPrimitivesPerLeaf; i++) {
+                const triangle tri = cx.tris[first + i];
+                if (isinf(tri.v[0].x())) break;
+                float u, v;
+                if (cx.cnt) cx.cnt->prim_tests++;
+                const float hitT = triangleHit(tri, r, t_min, closest, u, v);
+                if (hitT < closest) {
+                    if (isShadow) return 0.0f;
+                    closest = hitT;
+                    rec.triId = first + i;
+                    rec.u = u;
+                    rec.v = v;
+                }
+            }
+            twin_pop(bitStack, idx);
+        }
+    }
+    return closest;
+}
+
+float twin_hit_mesh(const ray& r, const MeshCtx& cx, float t_min, float t_max, tri_hit& rec, bool primary, bool isShadow) {   /* kernels.cu:296-323 */
+    if (!hit_bbox(cx.bounds.min, cx.bounds.max, r, t_max)) {
+        if (isShadow) cx.stat(RT_STAT_SHADOWS_BBOX_NOHITS);
+        else cx.stat(primary ? RT_STAT_PRIMARY_BBOX_NOHITS : RT_STAT_SECONDARY_BBOX_NOHIT);
+        return FLT_MAX;
+    }
+    return twin_hit_bvh(r, cx, t_min, t_max, rec, isShadow);
+}
+
+bool twin_hit(const MeshCtx& cx, const path& p, float t_max, bool isShadow, intersection& inters) {             /* kernels.cu:325-360 */
+    const ray r = isShadow ? ray(p.origin, p.shadowDir) : ray(p.origin, p.rayDir);
+    tri_hit triHit;
+    const bool primary = p.bounce == 0;
+    inters.objId = T_NONE;
+    if ((inters.t = twin_hit_mesh(r, cx, cx.epsilon, t_max, triHit, primary, isShadow)) < t_max) {
+        if (isShadow) return true;
+        inters.objId = T_TRIMESH;
+        triangle tri = cx.tris[triHit.triId];
+        inters.meshID = tri.meshID;
+        inters.normal = unit_vector(cross(tri.v[1] - tri.v[0], tri.v[2] - tri.v[0]));
+        inters.texCoords[0] = (triHit.u * tri.texCoords[1 * 2 + 0] + triHit.v * tri.texCoords[2 * 2 + 0] + (1 - triHit.u - triHit.v) * tri.texCoords[0 * 2 + 0]);
+        inters.texCoords[1] = (triHit.u * tri.texCoords[1 * 2 + 1] + triHit.v * tri.texCoords[2 * 2 + 1] + (1 - triHit.u - triHit.v) * tri.texCoords[0 * 2 + 1]);
+    } else {
+        if (isShadow) return false;
+        if (cx.use_floor && (inters.t = planeHit(cx.floor, r, cx.epsilon, FLT_MAX)) < FLT_MAX) {   /* the call site of kernels.cu:341-345, re-enabled */
+            inters.objId = T_PLANE;
+            inters.normal = cx.floor.norm;
+        } else
+        if (p.specular && sphereHit(cx.light, r, cx.epsilon, t_max) < t_max) {
+            inters.objId = T_LIGHT;
+            return true;
+        }
+    }
+    if (inters.objId != T_NONE) {
+        inters.p = r.point_at_parameter(inters.t);
+        if (dot(r.direction(), inters.normal) > 0.0f)
+            inters.normal = -inters.normal;
+        return true;
+    }
+    return false;
+}
+
+bool twin_generate_shadow_ray(const MeshCtx& cx, path& p, const intersection& inters, float& lightDist, float* cosAMax_out) {   /* kernels.cu:363-393 */
+    const vec3 sw = unit_vector(cx.light.center - p.origin);
+    const vec3 su = unit_vector(cross(fabs(sw.x()) > 0.01f ? vec3(0, 1, 0) : vec3(1, 0, 0), sw));
+    const vec3 sv = cross(sw, su);
+    const float cosAMax = sqrt(1.0f - cx.light.radius * cx.light.radius / (p.origin - cx.light.center).squared_length());
+    if (cosAMax_out) *cosAMax_out = cosAMax;
+    if (isnan(cosAMax)) return false;
+    const float eps1 = rnd(p.rng);
+    const float eps2 = rnd(p.rng);
+    const float cosA = 1.0f - eps1 + eps1 * cosAMax;
+    const float sinA = sqrt(1.0f - cosA * cosA);
+    const float phi = 2 * M_PI * eps2;
+    const vec3 l = su * cosf(phi) * sinA + sv * sinf(phi) * sinA + sw * cosA;
+    const float dotl = dot(l, inters.normal);
+    if (dotl <= 0)
+        return false;
+    p.shadowDir = unit_vector(l);
+    const float omega = 2 * M_PI * (1.0f - cosAMax);
+    p.lightContribution = p.attenuation * cx.lightColor * dotl * omega / M_PI;
+    lightDist = (cx.light.center - p.origin).length() - cx.light.radius;
+    return true;
+}
+
+void twin_scatter(scatter_info& sc, const intersection& in, const vec3& wo, const material& m, const vec3& albedo, rand_state& rng) {
+    switch ((int)m.type) {                                           /* additive preset types call the reference's own preset functions */
+    case RT_FLOOR_COAT:        floor_coat_scatter(sc, in, wo, rng); break;
+    case RT_FLOOR_DIFFUSE:     floor_diffuse_scatter(sc, in, wo, rng); break;
+    case RT_FLOOR_CHECKER:     floor_checker_scatter(sc, in, wo, rng); break;
+    case RT_MODEL_COAT:        model_coat_scatter(sc, in, wo, rng); break;
+    case RT_MODEL_DIFFUSE:     model_diffuse_scatter(sc, in, wo, rng); break;
+    case RT_MODEL_GLOSSY:      model_glossy_scatter(sc, in, wo, rng); break;
+    case RT_MODEL_GLASS:       model_glass_scatter(sc, in, wo, rng); break;
+    case RT_MODEL_TINTEDGLASS: model_tintedglass_scatter(sc, in, wo, rng); break;
+    case RT_MODEL_SSS:         model_sss_scatter(sc, in, wo, rng); break;
+    default:                   material_scatter(sc, in, wo, m, albedo, rng); break;     /* kernels.cu:480 */
+    }
+}
+
+void twin_color(const MeshCtx& cx, path& p) {                                                                    /* kernels.cu:396-533 */
+    p.attenuation = vec3(1.0, 1.0, 1.0);
+    p.color = vec3(0, 0, 0);
+    bool fromMesh = false;
+    for (p.bounce = 0; p.bounce < cx.maxDepth; p.bounce++) {
+        const bool primary = p.bounce == 0;
+        cx.stat(primary ? RT_STAT_PRIMARY : RT_STAT_SECONDARY);
+        if (fromMesh) cx.stat(RT_STAT_SECONDARY_MESH);
+        if (p.attenuation.length() < 0.01f) cx.stat(RT_STAT_LOW_POWER);
+        if (cx.cnt) cx.cnt->rays++;
+        intersection inters;
+        if (!twin_hit(cx, p, FLT_MAX, false, inters)) {
+            if (primary) cx.stat(RT_STAT_PRIMARY_NOHITS);
+            else cx.stat(fromMesh ? RT_STAT_SECONDARY_MESH_NOHIT : RT_STAT_SECONDARY_NOHIT);
+            if (cx.gradient_sky) {                                   /* kernels.cu:419-421 */
+                float t = 0.5f * (p.rayDir.y() + 1.0f);
+                vec3 c = (1.0f - t) * vec3(1.0, 1.0, 1.0) + t * vec3(0.5, 0.7, 1.0);
+                p.color += p.attenuation * c;
+            } else {
+                p.color += p.attenuation * vec3(0.5f, 0.5f, 0.5f);   /* kernels.cu:424 */
+            }
+            return;
+        }
+        if (cx.cnt) cx.cnt->hits++;
+        fromMesh = (inters.objId == T_TRIMESH);
+        if (primary && !fromMesh) cx.stat(RT_STAT_PRIMARY_NOHITS);
+        if (primary && fromMesh) cx.stat(RT_STAT_PRIMARY_HIT_MESH);
+        if (inters.objId == T_LIGHT) {
+            if (!cx.shadow) p.color += p.attenuation * cx.lightColor;   /* kernels.cu:440-446 */
+            return;
+        }
+        inters.inside = p.inside;
+        scatter_info scatter(inters);
+        if (inters.objId == T_TRIMESH) {
+            const material& mat = cx.materials[inters.meshID];
+            vec3 albedo;
+            if (mat.texId != -1) {                                   /* kernels.cu:456-476 */
+                int texId = mat.texId;
+                int width = cx.textures[texId].width;
+                int height = cx.textures[texId].height;
+                float tu = inters.texCoords[0];
+                tu = tu - floorf(tu);
+                float tv = inters.texCoords[1];
+                tv = tv - floorf(tv);
+                const int tx = (width - 1) * tu;
+                const int ty = (height - 1) * tv;
+                const int tIdx = ty * width + tx;
+                albedo = vec3(cx.textures[texId].data[tIdx * 3 + 0], cx.textures[texId].data[tIdx * 3 + 1], cx.textures[texId].data[tIdx * 3 + 2]);
+            } else {
+                albedo = mat.color;
+            }
+            twin_scatter(scatter, inters, p.rayDir, cx.materials[inters.meshID], albedo, p.rng);
+        } else
+            floor_diffuse_scatter(scatter, inters, p.rayDir, p.rng);   /* kernels.cu:481-482 */
+
+        p.origin += scatter.t * p.rayDir;
+        p.rayDir = scatter.wi;
+        p.attenuation *= scatter.throughput;
+        p.specular = scatter.specular;
+        p.inside = scatter.refracted ? !p.inside : p.inside;
+        if (cx.shadow) {                                             /* kernels.cu:490-511 */
+            float lightDist;
+            if (!p.specular && twin_generate_shadow_ray(cx, p, inters, lightDist, nullptr)) {
+                if (cx.cnt) cx.cnt->shadow_rays++;
+                cx.stat(RT_STAT_SHADOWS);
+                if (!twin_hit(cx, p, lightDist, true, inters)) {
+                    cx.stat(RT_STAT_SHADOWS_NOHITS);
+                    p.color += p.lightContribution;
+                }
+            }
+        }
+        if (cx.russian_roulette) {                                   /* kernels.cu:512-527 */
+            if (p.bounce > 3) {
+                float m = max(p.attenuation);
+                if (rnd(p.rng) > m) { cx.stat(RT_STAT_RUSSIAN_KILL); return; }
+                p.attenuation *= 1 / m;
+            }
+        }
+    }
+    cx.stat(RT_STAT_EXCEED_MAX_BOUNCE);
+}
+
+MeshCtx make_ctx(const rt_render_options* opt, int max_depth, orc_counters* cnt) {
+    MeshCtx cx;
+    memset((void*)&cx, 0, sizeof cx);
+    cx.maxDepth = max_depth > 255 ? 255 : max_depth;
+    memcpy((void*)&cx.light, &opt->light, sizeof cx.light);
+    memcpy((void*)&cx.lightColor, &opt->lightColor, sizeof cx.lightColor);
+    cx.shadow = opt->nee != 0; cx.russian_roulette = opt->rr != 0; cx.gradient_sky = opt->sky == RT_SKY_GRADIENT;
+    cx.use_floor = opt->floor != 0;
+    cx.epsilon = opt->t_min;
+    cx.cnt = cnt;
+    return cx;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_generate_shadow_ray(const rt_render_options* opt, const float origin[3], const float attenuation[3], const float normal[3],
+                            uint32_t* rng, float out9[9]) {
+    MeshCtx cx = make_ctx(opt, 1, nullptr);
+    path p;
+    p.origin = V(origin); p.attenuation = V(attenuation); p.rng = *rng;
+    p.shadowDir = vec3(0, 0, 0); p.lightContribution = vec3(0, 0, 0);
+    intersection in; memset((void*)&in, 0, sizeof in);
+    in.normal = V(normal);
+    float lightDist = 0.0f, cosAMax = 0.0f;
+    uint32_t probe = p.rng;
+    const bool ok = twin_generate_shadow_ray(cx, p, in, lightDist, &cosAMax);
+    int draws = 0;
+    while (probe != p.rng && draws < 4) { xor_shift_32(probe); draws++; }
+    S(out9, p.shadowDir); S(out9 + 3, p.lightContribution);
+    out9[6] = lightDist; out9[7] = cosAMax; out9[8] = (float)draws;
+    *rng = p.rng;
+    return ok ? 1 : 0;
+}
+
+void ref_render_mesh(const rt_triangle* tris_, const rt_bvh_node* bvh_, int num_bvh_nodes, const float bounds6[6], int nppl,
+                     const rt_plane* floor_, const rt_material* mats_, const rt_stexture* textures_,
+                     const rt_camera* cam_, const rt_render_options* opt,
+                     int nx, int ny, int ns, int max_depth,
+                     int x0, int y0, int x1, int y1, rt_vec3* fb_, orc_counters* cnt) {                   /* render(), kernels.cu:535-569 */
+    MeshCtx cx = make_ctx(opt, max_depth, cnt);
+    cx.tris = reinterpret_cast<const triangle*>(tris_);
+    cx.bvh = reinterpret_cast<const bvh_node*>(bvh_);
+    cx.firstLeafIdx = num_bvh_nodes / 2;
+    cx.numPrimitivesPerLeaf = nppl;
+    cx.bounds = bbox(V(bounds6), V(bounds6 + 3));
+    if (floor_) memcpy((void*)&cx.floor, floor_, sizeof cx.floor);
+    cx.materials = reinterpret_cast<const material*>(mats_);
+    cx.textures = textures_;
+    camera cam; memcpy((void*)&cam, cam_, sizeof cam);
+    vec3* fb = reinterpret_cast<vec3*>(fb_);
+    for (int j = y0; j < y1; j++)
+        for (int i = x0; i < x1; i++) {
+            path p;
+            uint64_t pixelId = j * nx + i;
+            p.rng = (wang_hash(pixelId) * 336343633) | 1;
+            vec3 col(0, 0, 0);
+            for (int s = 0; s < ns; s++) {
+                if (opt->rng == RT_RNG_COUNTER) p.rng = (wang_hash((uint32_t)pixelId + wang_hash((uint32_t)s) * 0x9E3779B9u) * 336343633) | 1;
+                float u = float(i + rnd(p.rng)) / float(nx);
+                float v = float(j + rnd(p.rng)) / float(ny);
+                ray r = get_ray(cam, u, v, p.rng);
+                p.origin = r.origin();
+                p.rayDir = r.direction();
+                p.specular = false;
+                p.inside = false;
+                twin_color(cx, p);
+                col += p.color;
+                if (cnt) cnt->samples++;
+                if (isnan(p.color)) cx.stat(RT_STAT_NAN);
             }
             fb[pixelId] = col / float(ns);
         }

@@ -439,6 +439,8 @@ typedef struct {
     int max_depth;
 } ctx_t;
 
+#define STAT(c, k) do { if ((c)->cnt) (c)->cnt->ref_stats[k]++; } while (0)     /* context.rayStat(), kernels.cu:103-105 */
+
 static inline void pop_bitstack(uint32_t* bitStack, int* idx) {     /* kernels.cu:148-152 */
     int m = __builtin_ffsll((long long)*bitStack) - 1;
     *bitStack = (*bitStack >> m) ^ 1u;
@@ -463,9 +465,11 @@ static float hit_bvh(const orc_scene* sc, const ray_t* r, float t_min, float t_m
             int traverseRight = rightHit < closest;
             int swap = rightHit < leftHit;
             if (traverseLeft && traverseRight) {
+                if (cnt) cnt->ref_stats[RT_STAT_NODES_BOTH]++;          /* BVH_COUNT, kernels.cu:184-186,219-222 */
                 idx = idx2 + (swap ? 1 : 0);
                 bitStack = (bitStack << 1) + 1;
             } else if (traverseLeft || traverseRight) {
+                if (cnt) cnt->ref_stats[RT_STAT_NODES_SINGLE]++;
                 idx = idx2 + (swap ? 1 : 0);
                 bitStack = bitStack << 1;
             } else {
@@ -498,9 +502,13 @@ float orc_hit_bvh(const orc_scene* sc, const float org[3], const float dir_in[3]
     return hit_bvh(sc, &r, t_min, t_max, is_shadow, tri_id, u, v, cnt);
 }
 
-static float hit_mesh(const ctx_t* c, const ray_t* r, float t_min, float t_max, int is_shadow,
+static float hit_mesh(const ctx_t* c, const ray_t* r, float t_min, float t_max, int is_shadow, int primary,
                       uint32_t* triId, float* hu, float* hv) {                           /* kernels.cu:296-323 */
-    if (!hit_bbox(ldv(c->sc->bounds.min), ldv(c->sc->bounds.max), r, t_max)) return FLT_MAX;
+    if (!hit_bbox(ldv(c->sc->bounds.min), ldv(c->sc->bounds.max), r, t_max)) {
+        if (is_shadow) STAT(c, RT_STAT_SHADOWS_BBOX_NOHITS);                             /* kernels.cu:298-301 */
+        else STAT(c, primary ? RT_STAT_PRIMARY_BBOX_NOHITS : RT_STAT_SECONDARY_BBOX_NOHIT);
+        return FLT_MAX;
+    }
     return hit_bvh(c->sc, r, t_min, t_max, is_shadow, triId, hu, hv, c->cnt);
 }
 
@@ -541,7 +549,8 @@ static int hit(const ctx_t* c, const path_t* p, float t_max, int is_shadow, inte
         }
     } else {
         uint32_t triId = 0; float hu = 0, hv = 0;
-        if ((in->t = hit_mesh(c, &r, eps, t_max, is_shadow, &triId, &hu, &hv)) < t_max) {
+        const int primary = p->bounce == 0;                                            /* kernels.cu:328 */
+        if ((in->t = hit_mesh(c, &r, eps, t_max, is_shadow, primary, &triId, &hu, &hv)) < t_max) {
             if (is_shadow) return 1;
             in->objId = OBJ_TRIMESH;
             const rt_triangle* tri = &c->sc->tris[triId];
@@ -551,6 +560,11 @@ static int hit(const ctx_t* c, const path_t* p, float t_max, int is_shadow, inte
             in->texCoords[1] = (hu * tri->texCoords[1 * 2 + 1] + hv * tri->texCoords[2 * 2 + 1] + (1 - hu - hv) * tri->texCoords[0 * 2 + 1]);
         } else {
             if (is_shadow) return 0;
+            /* kernels.cu:341-345: the floor, commented out at HEAD; rt_render_options.floor = 1 re-enables the call site */
+            if (c->opt->floor && (in->t = plane_hit(&c->sc->floor, &r, eps, FLT_MAX)) < FLT_MAX) {
+                in->objId = OBJ_PLANE;
+                in->normal = ldv(c->sc->floor.norm);
+            } else
             if (p->specular && sphere_hit(&c->opt->light, &r, eps, t_max) < t_max) {   /* kernels.cu:346 */
                 in->objId = OBJ_LIGHT;
                 return 1;
@@ -558,21 +572,22 @@ static int hit(const ctx_t* c, const path_t* p, float t_max, int is_shadow, inte
         }
     }
     if (in->objId != OBJ_NONE) {
-        if (in->objId == OBJ_TRIMESH) in->p = point_at(&r, in->t);
+        if (in->objId == OBJ_TRIMESH || in->objId == OBJ_PLANE) in->p = point_at(&r, in->t);
         if (dot(r.B, in->normal) > 0.0f) in->normal = neg(in->normal);
         return 1;
     }
     return 0;
 }
 
-static int generate_shadow_ray(const ctx_t* c, path_t* p, const inters_t* in, float* lightDist) {  /* kernels.cu:363-393 */
-    const rt_sphere* light = &c->opt->light;
+static int generate_shadow_ray(const rt_render_options* opt, path_t* p, v3 normal, float* lightDist, float* cosAMax_out) {  /* kernels.cu:363-393 */
+    const rt_sphere* light = &opt->light;
     const v3 lc = ldv(light->center);
     const v3 sw = unit(sub(lc, p->origin));
     const v3 su = unit(cross(fabsf(sw.x) > 0.01f ? V(0, 1, 0) : V(1, 0, 0), sw));
     const v3 sv = cross(sw, su);
 
     const float cosAMax = sqrtf(1.0f - light->radius * light->radius / sqlen(sub(p->origin, lc)));
+    if (cosAMax_out) *cosAMax_out = cosAMax;
     if (isnan(cosAMax)) return 0;
 
     const float eps1 = rnd(&p->rng);
@@ -582,25 +597,47 @@ static int generate_shadow_ray(const ctx_t* c, path_t* p, const inters_t* in, fl
     const float phi = (float)(2 * M_PI * (double)eps2);                  /* :378 double product, narrowed */
     const v3 l = add(add(muls(sinA, muls(cosf(phi), su)), muls(sinA, muls(sinf(phi), sv))), muls(cosA, sw));
 
-    const float dotl = dot(l, in->normal);
+    const float dotl = dot(l, normal);
     if (dotl <= 0) return 0;
 
     p->shadowDir = unit(l);
     const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));    /* :386 */
-    p->lightContribution = divs(muls(omega, muls(dotl, mulv(p->attenuation, ldv(c->opt->lightColor)))), (float)M_PI); /* :387 */
+    p->lightContribution = divs(muls(omega, muls(dotl, mulv(p->attenuation, ldv(opt->lightColor)))), (float)M_PI); /* :387 */
     *lightDist = len(sub(lc, p->origin)) - light->radius;
     return 1;
+}
+
+int orc_generate_shadow_ray(const rt_render_options* opt, const float origin[3], const float attenuation[3], const float normal[3],
+                            uint32_t* rng, float out9[9]) {
+    path_t p; memset(&p, 0, sizeof p);
+    p.origin = ld(origin); p.attenuation = ld(attenuation); p.rng = *rng;
+    uint64_t draws = 0, *saved = g_draws;
+    g_draws = &draws;
+    float lightDist = 0.0f, cosAMax = 0.0f;
+    const int ok = generate_shadow_ray(opt, &p, ld(normal), &lightDist, &cosAMax);
+    g_draws = saved;
+    st(out9, p.shadowDir); st(out9 + 3, p.lightContribution);
+    out9[6] = lightDist; out9[7] = cosAMax; out9[8] = (float)draws;
+    *rng = p.rng;
+    return ok;
 }
 
 static void color(const ctx_t* c, path_t* p) {                                          /* kernels.cu:396-533 */
     p->attenuation = V(1.0f, 1.0f, 1.0f);
     p->color = V(0, 0, 0);
     const int maxDepth = c->max_depth > 255 ? 255 : c->max_depth;       /* uint8_t bounce, helper_structs.h:58 */
+    int fromMesh = 0;                                                   /* STATS, kernels.cu:399-401 */
     for (p->bounce = 0; p->bounce < maxDepth; p->bounce++) {
+        const int primary = p->bounce == 0;                             /* STATS, kernels.cu:403-408 */
+        STAT(c, primary ? RT_STAT_PRIMARY : RT_STAT_SECONDARY);
+        if (fromMesh) STAT(c, RT_STAT_SECONDARY_MESH);
+        if (len(p->attenuation) < 0.01f) STAT(c, RT_STAT_LOW_POWER);
         inters_t in; memset(&in, 0, sizeof in);
         int sid = -1;
         if (c->cnt) c->cnt->rays++;
         if (!hit(c, p, FLT_MAX, 0, &in, &sid)) {
+            if (primary) STAT(c, RT_STAT_PRIMARY_NOHITS);               /* kernels.cu:414-417 */
+            else STAT(c, fromMesh ? RT_STAT_SECONDARY_MESH_NOHIT : RT_STAT_SECONDARY_NOHIT);
             if (c->opt->sky == RT_SKY_GRADIENT) {                       /* kernels.cu:419-421 */
                 float t = 0.5f * (p->rayDir.y + 1.0f);
                 v3 sky = add(muls((1.0f - t), V(1.0f, 1.0f, 1.0f)), muls(t, V(0.5f, 0.7f, 1.0f)));
@@ -611,6 +648,9 @@ static void color(const ctx_t* c, path_t* p) {                                  
             return;
         }
         if (c->cnt) c->cnt->hits++;
+        fromMesh = (in.objId == OBJ_TRIMESH || in.objId == OBJ_SPHERE); /* kernels.cu:428-432 (a sphere scene's spheres are its mesh) */
+        if (primary && !fromMesh) STAT(c, RT_STAT_PRIMARY_NOHITS);
+        if (primary && fromMesh) STAT(c, RT_STAT_PRIMARY_HIT_MESH);
         if (in.objId == OBJ_LIGHT) {                                    /* kernels.cu:433-447 */
             if (!c->opt->nee)                                           /* #ifndef SHADOW branch, :444-445 */
                 p->color = add(p->color, mulv(p->attenuation, ldv(c->opt->lightColor)));
@@ -622,7 +662,7 @@ static void color(const ctx_t* c, path_t* p) {                                  
         if (in.objId == OBJ_SPHERE) {
             const rt_material* mat = &c->sc->sphere_materials[sid];
             material_scatter(&sc, &in, p->rayDir, mat, ldv(mat->color), &p->rng);
-        } else {                                                        /* kernels.cu:452-480 */
+        } else if (in.objId == OBJ_TRIMESH) {                           /* kernels.cu:452-480 */
             const rt_material* mat = &c->sc->materials[in.meshID];
             v3 albedo;
             if (mat->texId != -1) {
@@ -642,6 +682,8 @@ static void color(const ctx_t* c, path_t* p) {                                  
                 albedo = ldv(mat->color);
             }
             material_scatter(&sc, &in, p->rayDir, mat, albedo, &p->rng);
+        } else {                                                        /* kernels.cu:481-482: the floor */
+            preset_scatter(&sc, &in, p->rayDir, RT_FLOOR_DIFFUSE, &p->rng);
         }
 
         p->origin = add(p->origin, muls(sc.t, p->rayDir));             /* kernels.cu:485-489 */
@@ -652,23 +694,27 @@ static void color(const ctx_t* c, path_t* p) {                                  
 
         if (c->opt->nee) {                                              /* kernels.cu:490-511 */
             float lightDist;
-            if (!p->specular && generate_shadow_ray(c, p, &in, &lightDist)) {
+            if (!p->specular && generate_shadow_ray(c->opt, p, in.normal, &lightDist, 0)) {
                 inters_t sh; memset(&sh, 0, sizeof sh);
                 int s2 = -1;
                 if (c->cnt) c->cnt->shadow_rays++;
-                if (!hit(c, p, lightDist, 1, &sh, &s2))
+                STAT(c, RT_STAT_SHADOWS);
+                if (!hit(c, p, lightDist, 1, &sh, &s2)) {
+                    STAT(c, RT_STAT_SHADOWS_NOHITS);
                     p->color = add(p->color, p->lightContribution);
+                }
             }
         }
         if (c->opt->rr) {                                               /* kernels.cu:512-527 */
             if (p->bounce > 3) {
                 float m = max3(p->attenuation);
-                if (rnd(&p->rng) > m) return;
+                if (rnd(&p->rng) > m) { STAT(c, RT_STAT_RUSSIAN_KILL); return; }
                 float k = 1 / m;
                 p->attenuation = V(p->attenuation.x * k, p->attenuation.y * k, p->attenuation.z * k); /* vec3.h:177-182 */
             }
         }
     }
+    STAT(c, RT_STAT_EXCEED_MAX_BOUNCE);                                 /* kernels.cu:529-531 */
 }
 
 void orc_render(const orc_scene* scn, const rt_camera* cam, const rt_render_options* opt,
@@ -694,6 +740,7 @@ void orc_render(const orc_scene* scn, const rt_camera* cam, const rt_render_opti
                 color(&c, &p);
                 col = add(col, p.color);
                 if (counters) counters->samples++;
+                if (counters && (isnan(p.color.x) || isnan(p.color.y) || isnan(p.color.z))) counters->ref_stats[RT_STAT_NAN]++;   /* kernels.cu:559-561 */
             }
             st(fb[pixelId].e, divs(col, (float)ns));
         }

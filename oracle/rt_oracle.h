@@ -38,6 +38,7 @@ typedef struct orc_scene {
     int32_t            num_materials;
     const rt_stexture* textures;
     int32_t            num_textures;
+    rt_plane           floor;              /* kernel_scene.floor; only read when rt_render_options.floor = 1 */
 } orc_scene;
 
 typedef struct orc_counters {
@@ -48,6 +49,7 @@ typedef struct orc_counters {
     uint64_t node_visits;   /* BVH internal nodes visited                     */
     uint64_t hits;
     uint64_t rng_draws;
+    uint64_t ref_stats[RT_STAT_COUNT];  /* the reference's `#ifdef STATS` counters, kernels.cu:47-67,399-561 (same indices) */
 } orc_counters;
 
 /* rnd.h */
@@ -96,6 +98,11 @@ void orc_material_scatter_p(float inters_t, const float p[3], const float normal
 /* kernels.cu:154-224; returns closest t (or t_max); *tri_id,*u,*v valid when result < t_max */
 float orc_hit_bvh(const orc_scene* sc, const float org[3], const float dir_in[3], float t_min, float t_max,
                   int is_shadow, uint32_t* tri_id, float* u, float* v, orc_counters* cnt);
+
+/* generateShadowRay, kernels.cu:363-393, on (path origin, path attenuation, shading normal, rng).  Returns 1 when a shadow ray is
+ * generated; out9 = {shadowDir xyz, lightContribution xyz, lightDist, cosAMax, draws consumed}; *rng is advanced. */
+int orc_generate_shadow_ray(const rt_render_options* opt, const float origin[3], const float attenuation[3], const float normal[3],
+                            uint32_t* rng, float out9[9]);
 
 /* kernels.cu:535-569 restricted to the pixel rectangle [x0,x1) x [y0,y1); fb is the FULL nx*ny
  * framebuffer (untouched outside the rectangle). counters may be NULL. */

@@ -101,3 +101,107 @@ def test_frames_random_configs(rt, scene, nx, ny, ns, kw):
     b, cb = O.ref_render_spheres(sp, mt, cam, opt, nx, ny, ns, 50, counters=True)
     assert np.array_equal(_bits(a), _bits(b))
     assert (ca.rays, ca.prim_tests, ca.hits) == (cb.rays, cb.prim_tests, cb.hits)
+
+
+# ---- the MESH path: oracle restatement vs the reference-arithmetic twin (oracle/ref_driver.cpp ref_render_mesh) ------------
+
+def _triangle_soup(rt, rng, n, n_mats=6):
+    tris = np.zeros(n, rt.triangle_dtype)
+    c = rng.uniform(-2, 2, (n, 1, 3)).astype(np.float32)
+    tris["v"] = c + rng.uniform(-0.7, 0.7, (n, 3, 3)).astype(np.float32)
+    tris["texCoords"] = rng.uniform(-1, 2, (n, 6))
+    tris["meshID"] = rng.integers(0, n_mats, n)
+    mats = np.zeros(n_mats, rt.material_dtype)
+    mats["type"] = [rt.RT_DIFFUSE, rt.RT_METAL, rt.RT_GLASS, rt.RT_DIFFUSE, rt.RT_METAL, rt.RT_MODEL_COAT][:n_mats]
+    mats["color"] = rng.uniform(0.2, 1, (n_mats, 3))
+    mats["param"] = [0.0, 0.1, 1.5, 0.0, 0.0, 0.0][:n_mats]
+    mats["texId"] = -1
+    return tris, mats
+
+
+def _same_counters(a, b):
+    return (a.samples, a.rays, a.shadow_rays, a.prim_tests, a.node_visits, a.hits) == \
+           (b.samples, b.rays, b.shadow_rays, b.prim_tests, b.node_visits, b.hits) and list(a.ref_stats) == list(b.ref_stats)
+
+
+@pytest.mark.parametrize("kw", [{}, {"nee": 0}, {"nee": 0, "rr": 0}, {"sky": 1}, {"floor": 1}, {"floor": 1, "nee": 0}, {"rng": 1},
+                                {"light_radius": 900.0}])
+def test_mesh_frames_oracle_equals_reference_twin_staircase(rt, kw):
+    """Frames + every counter, NEE on and off, RR on and off, gradient sky, the floor call site re-enabled (kernels.cu:341-345),
+    counter RNG, and a light so big that cosAMax is NaN for part of the scene (kernels.cu:371-372)."""
+    tris, mats = rt.scene_staircase_procedural(1)
+    hm = rt.HostMesh.build(tris, 5)
+    nx, ny, ns = 64, 80, 2
+    cam = rt.staircase_camera(nx, ny)
+    opt = O.default_options(False)
+    kw = dict(kw)
+    if "light_radius" in kw:
+        opt.light.radius = kw.pop("light_radius")
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    lo = np.array(hm.view.bounds.min.e[:])
+    floor = (0.0, 1.0, 0.0, 0.0, float(lo[1]) - 5.0, 0.0)                 # plane(point, norm): norm first (helper_structs.h:165-171)
+    sc = O.mesh_scene(hm, mats, floor=floor)
+    a, ca = O.render(sc, cam, opt, nx, ny, ns, 64, counters=True)
+    b, cb = O.ref_render_mesh(sc, cam, opt, nx, ny, ns, 64, counters=True)
+    assert np.array_equal(_bits(a), _bits(b)), np.count_nonzero(_bits(a) != _bits(b))
+    assert _same_counters(ca, cb)
+    assert ca.ref_stats[rt.RT_STAT_PRIMARY] == nx * ny * ns and ca.ref_stats[rt.RT_STAT_PRIMARY] + ca.ref_stats[rt.RT_STAT_SECONDARY] == ca.rays
+    if opt.nee:
+        assert ca.ref_stats[rt.RT_STAT_SHADOWS] == ca.shadow_rays > 0
+
+
+@pytest.mark.parametrize("n,nppl,nee,floor", [(1, 1, 1, 0), (7, 5, 1, 1), (65, 3, 0, 1), (1000, 5, 1, 0), (1000, 16, 0, 0), (300, 20, 1, 1)])
+def test_mesh_frames_oracle_equals_reference_twin_soups(rt, n, nppl, nee, floor):
+    rng = np.random.default_rng(777 + 13 * n + nppl)
+    tris, mats = _triangle_soup(rt, rng, n)
+    tex = [rng.uniform(0, 1, (9, 13, 3)).astype(np.float32)]
+    mats["texId"][3] = 0
+    hm = rt.HostMesh.build(tris, nppl)
+    nx, ny, ns = 56, 40, 3
+    cam = rt.make_camera((4.5, 2.5, 6.0), (0, 0, 0), (0, 1, 0), 40.0, nx / ny, 0.02, 8.0)
+    opt = O.default_options(False)
+    opt.nee = nee
+    opt.light.center.e[:] = (3.0, 9.0, 2.0); opt.light.radius = 1.5       # a light the soup can actually shadow
+    opt.floor = floor
+    sc = O.mesh_scene(hm, mats, tex, floor=(0.0, 1.0, 0.0, 0.0, -3.0, 0.0))   # plane {norm, point} (helper_structs.h:165-171)
+    a, ca = O.render(sc, cam, opt, nx, ny, ns, 12, counters=True)
+    b, cb = O.ref_render_mesh(sc, cam, opt, nx, ny, ns, 12, counters=True)
+    assert np.array_equal(_bits(a), _bits(b)), np.count_nonzero(_bits(a) != _bits(b))
+    assert _same_counters(ca, cb)
+    if floor:       # primary rays that hit only the floor count as "primary nohit" (kernels.cu:430); paths leaving the floor into the sky as "secondary no hit"
+        assert ca.ref_stats[rt.RT_STAT_SECONDARY_NOHIT] > 0 and ca.ref_stats[rt.RT_STAT_PRIMARY_NOHITS] > 0
+    else:
+        assert ca.ref_stats[rt.RT_STAT_SECONDARY_NOHIT] == 0
+
+
+def test_generate_shadow_ray_oracle_equals_reference_twin(rt):
+    """generateShadowRay as a whole (kernels.cu:363-393) on tabulated (origin, attenuation, normal, rng): every output bit-equal,
+    incl. the NaN early-out before any draw and the dotl <= 0 rejection after two draws."""
+    rng = np.random.default_rng(5)
+    opt = O.default_options(False)
+    n_gen = n_nan = n_rej = 0
+    for k in range(3000):
+        if k % 10 == 9:                                   # inside the light's sphere: cosAMax = NaN
+            org = np.array(opt.light.center.e[:]) + rng.normal(size=3) * 20.0
+        else:
+            org = rng.uniform(-300, 300, 3) + (0, 100, 0)
+        att = rng.uniform(0, 1, 3)
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        if k % 3 == 0:                                    # facing the light more often than not
+            nrm = np.array(opt.light.center.e[:]) - org; nrm /= np.linalg.norm(nrm)
+        seed = int(rng.integers(1, 2 ** 32)) | 1
+        ra = O.generate_shadow_ray(opt, org, att, nrm, seed, "orc")
+        rb = O.generate_shadow_ray(opt, org, att, nrm, seed, "ref")
+        assert ra[0] == rb[0] and ra[5] == rb[5] and ra[6] == rb[6], k
+        assert np.array_equal(_bits(ra[4]), _bits(rb[4]))                                     # cosAMax (NaN included: same bits)
+        if ra[0]:
+            n_gen += 1
+            assert np.array_equal(_bits(ra[1]), _bits(rb[1])) and np.array_equal(_bits(ra[2]), _bits(rb[2])) and _bits(ra[3]) == _bits(rb[3]), k
+        elif ra[5] == 0:
+            n_nan += 1
+            assert np.isnan(ra[4])
+        else:
+            n_rej += 1
+            assert ra[5] == 2
+    assert n_gen > 500 and n_nan > 100 and n_rej > 100
