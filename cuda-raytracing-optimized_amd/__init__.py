@@ -449,7 +449,7 @@ def rmse(f, g):
 # per-function device probes (include/rt_probe.h)
 # ---------------------------------------------------------------------------------------------
 
-PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math")
+PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math", "ShadowRay", "PlaneHit")
                  for m in ("parity", "fast")]
 
 
@@ -526,6 +526,20 @@ class Probe:
         self._fn("Scatter")(_p(t), _p(hp), _p(normal), _p(inside), _p(wo), _p(mats), _p(color), _p(st), C.c_int(n),
                             _p(wi), _p(thr), _p(flags), _p(tout), _p(sa))
         return wi, thr, flags, tout, sa
+
+    def shadow_ray(self, light, light_color, org, atten, normal, states):
+        """generateShadowRay (kernels.cu:363-393). Returns (generated, shadowDir, lightContribution, lightDist, cosAMax, draws, state_after)."""
+        org = _f32(org); atten = _f32(atten); normal = _f32(normal); st = _u32(states); n = len(st)
+        out = np.zeros((n, 9), np.float32); ok = np.zeros(n, np.int32); sa = np.zeros(n, np.uint32)
+        self._fn("ShadowRay")(C.byref(light), C.byref(light_color), _p(org), _p(atten), _p(normal), _p(st), C.c_int(n), _p(out), _p(ok), _p(sa))
+        return ok, out[:, 0:3], out[:, 3:6], out[:, 6], out[:, 7], out[:, 8].astype(np.int32), sa
+
+    def plane_hit(self, planes, org, dirs, tmin, tmax):
+        pl = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 6); n = len(pl)
+        org = _f32(org); dirs = _f32(dirs); tmin = _f32(tmin); tmax = _f32(tmax)
+        out = np.zeros(n, np.float32)
+        self._fn("PlaneHit")(_p(pl), _p(org), _p(dirs), _p(tmin), _p(tmax), C.c_int(n), _p(out))
+        return out
 
     def math(self, a, b):
         a = _f32(a); b = _f32(b); n = len(a)

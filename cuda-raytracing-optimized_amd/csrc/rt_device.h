@@ -327,5 +327,51 @@ __device__ __forceinline__ float sphere_hit(f3 center, float radius, const Ray& 
     return FLT_MAX;
 }
 
+__device__ __forceinline__ float plane_hit(f3 norm, f3 point, const Ray& r, float t_min, float t_max) {   // intersections.h:43-52
+    const float denom = dot(norm, r.d);
+    if (denom > -0.000001f) return FLT_MAX;
+    const f3 po = point - r.o;
+    const float t = dot(po, norm) / denom;
+    if (t < t_min || t > t_max) return FLT_MAX;
+    return t;
+}
+
+// ---- generateShadowRay, kernels.cu:363-393 ------------------------------------------------------------------------
+// Samples the spherical light by solid angle from the path's (already advanced) origin.  Returns false BEFORE any draw when
+// cosAMax is NaN (origin inside the light's sphere, :371-372), false AFTER exactly two draws when the sampled direction is
+// below the surface (:382-383).  `2 * M_PI * x` is a double product narrowed to float at the same two places as the
+// reference (:378, :386); `/ M_PI` divides by (float)M_PI (vec3.h:79).  cosf/sinf: OCML's fp32 sincosf here, glibc on the CPU
+// side - the only place where this function may differ from the oracle (<= 2 ulp in shadowDir; tolerance stated in the tests).
+struct ShadowSample {
+    f3 dir;             // p.shadowDir
+    f3 contrib;         // p.lightContribution
+    float dist;         // lightDist
+    float cosAMax;
+};
+
+__device__ __forceinline__ bool generate_shadow_ray(f3 lightC, float lightR, f3 lightColor, f3 org, f3 atten, f3 normal,
+                                                    uint32_t& rng, ShadowSample& out) {
+    const f3 sw = unit(lightC - org);
+    const f3 su = unit(cross(fabsf(sw.x) > 0.01f ? F3(0, 1, 0) : F3(1, 0, 0), sw));
+    const f3 sv = cross(sw, su);
+    const float cosAMax = rt_sqrt(1.0f - lightR * lightR / sqlen(org - lightC));
+    out.cosAMax = cosAMax;
+    if (isnan(cosAMax)) return false;
+    const float eps1 = rnd(rng);
+    const float eps2 = rnd(rng);
+    const float cosA = 1.0f - eps1 + eps1 * cosAMax;
+    const float sinA = rt_sqrt(1.0f - cosA * cosA);
+    const float phi = (float)(2 * M_PI * (double)eps2);
+    float sphi, cphi;
+    sincosf(phi, &sphi, &cphi);
+    const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
+    const float dotl = dot(l, normal);
+    if (!(dotl > 0)) return false;
+    out.dir = unit(l);
+    const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));
+    out.contrib = (omega * (dotl * (atten * lightColor))) / (float)M_PI;
+    out.dist = len(lightC - org) - lightR;
+    return true;
+}
 
 }  // namespace rtd

@@ -198,32 +198,14 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) 
             specular = sc.specular;
             inside = sc.refracted ? !inside : inside;
 
-            if (P.nee && !specular) {                                // generateShadowRay, kernels.cu:363-393
-                const f3 sw = unit(lightC - org);
-                const f3 su = unit(cross(fabsf(sw.x) > 0.01f ? F3(0, 1, 0) : F3(1, 0, 0), sw));
-                const f3 sv = cross(sw, su);
-                const float cosAMax = rt_sqrt(1.0f - lightR * lightR / sqlen(org - lightC));
-                if (!isnan(cosAMax)) {
-                    const float eps1 = rnd(rng);
-                    const float eps2 = rnd(rng);
-                    const float cosA = 1.0f - eps1 + eps1 * cosAMax;
-                    const float sinA = rt_sqrt(1.0f - cosA * cosA);
-                    const float phi = (float)(2 * M_PI * (double)eps2);
-                    float sphi, cphi;
-                            sincosf(phi, &sphi, &cphi);   // OCML fp32 (<= 2 ulp); glibc's cosf/sinf on the CPU side differ by ulps: tolerance, see tests
-                    const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
-                    const float dotl = dot(l, normal);
-                    if (dotl > 0) {
-                        const f3 shadowDir = unit(l);
-                        const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));
-                        const f3 contrib = (omega * (dotl * (atten * ld3(P.lightColor)))) / (float)M_PI;
-                        const float lightDist = len(lightC - org) - lightR;
-                        const Ray sr = make_ray(org, shadowDir);
-                        uint32_t tid2 = 0; float u2, v2;
-                        nshadow++;
-                        const float ts = hit_mesh(P, sr, eps, lightDist, true, tid2, u2, v2, st);
-                        if (!(ts < lightDist)) pcolor = pcolor + contrib;    // kernels.cu:504-510
-                    }
+            if (P.nee && !specular) {                                // generateShadowRay, kernels.cu:363-393 (rt_device.h)
+                ShadowSample sh;
+                if (generate_shadow_ray(lightC, lightR, ld3(P.lightColor), org, atten, normal, rng, sh)) {
+                    const Ray sr = make_ray(org, sh.dir);
+                    uint32_t tid2 = 0; float u2, v2;
+                    nshadow++;
+                    const float ts = hit_mesh(P, sr, eps, sh.dist, true, tid2, u2, v2, st);
+                    if (!(ts < sh.dist)) pcolor = pcolor + sh.contrib;       // kernels.cu:504-510
                 }
             }
             if (P.rr && bounce > 3) {                                // kernels.cu:512-527
@@ -422,31 +404,15 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     inside = sc.refracted ? !inside : inside;
 
                     bool shadow_job = false;
-                    if (P.nee && !specular) {                        // generateShadowRay, kernels.cu:363-393
-                        const f3 sw = unit(lightC - org);
-                        const f3 su = unit(cross(fabsf(sw.x) > 0.01f ? F3(0, 1, 0) : F3(1, 0, 0), sw));
-                        const f3 sv = cross(sw, su);
-                        const float cosAMax = rt_sqrt(1.0f - lightR * lightR / sqlen(org - lightC));
-                        if (!isnan(cosAMax)) {
-                            const float eps1 = rnd(rng);
-                            const float eps2 = rnd(rng);
-                            const float cosA = 1.0f - eps1 + eps1 * cosAMax;
-                            const float sinA = rt_sqrt(1.0f - cosA * cosA);
-                            const float phi = (float)(2 * M_PI * (double)eps2);
-                            float sphi, cphi;
-                            sincosf(phi, &sphi, &cphi);   // OCML fp32 (<= 2 ulp); glibc's cosf/sinf on the CPU side differ by ulps: tolerance, see tests
-                            const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
-                            const float dotl = dot(l, normal);
-                            if (dotl > 0) {
-                                const f3 shadowDir = unit(l);
-                                const float omega = (float)(2 * M_PI * (double)(1.0f - cosAMax));
-                                pend_contrib = (omega * (dotl * (atten * ld3(P.lightColor)))) / (float)M_PI;
-                                pend_dist = len(lightC - org) - lightR;
-                                nshadow++;
-                                shadow_dir = shadowDir;
-                                want_job = 2;                        // hit(context, p, lightDist, true, ...)
-                                shadow_job = true;
-                            }
+                    if (P.nee && !specular) {                        // generateShadowRay, kernels.cu:363-393 (rt_device.h)
+                        ShadowSample sh;
+                        if (generate_shadow_ray(lightC, lightR, ld3(P.lightColor), org, atten, normal, rng, sh)) {
+                            pend_contrib = sh.contrib;
+                            pend_dist = sh.dist;
+                            nshadow++;
+                            shadow_dir = sh.dir;
+                            want_job = 2;                            // hit(context, p, lightDist, true, ...)
+                            shadow_job = true;
                         }
                     }
                     if (!shadow_job) next_ray = true;                // falls through to Russian roulette below

@@ -141,9 +141,49 @@ __global__ void k_math(const float* a, const float* b, int n, float* quot, float
     stv(unit3, k, unit(F3(a[k], b[k], a[k] - b[k])));
 }
 
+__global__ void k_shadow_ray(rt_sphere light, rt_vec3 lightColor, const float* org, const float* atten, const float* normal,
+                             const uint32_t* states, int n, float* out9, int* ok, uint32_t* st_after) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t st = states[k];
+    ShadowSample s;
+    s.dir = F3(0, 0, 0); s.contrib = F3(0, 0, 0); s.dist = 0.0f; s.cosAMax = 0.0f;
+    const bool g = generate_shadow_ray(ld3(light.center), light.radius, ld3(lightColor), ld(org, k), ld(atten, k), ld(normal, k), st, s);
+    uint32_t probe = states[k];
+    int draws = 0;
+    while (probe != st && draws < 4) { (void)rnd(probe); draws++; }
+    float* o = out9 + 9 * k;
+    o[0] = s.dir.x; o[1] = s.dir.y; o[2] = s.dir.z; o[3] = s.contrib.x; o[4] = s.contrib.y; o[5] = s.contrib.z;
+    o[6] = s.dist; o[7] = s.cosAMax; o[8] = (float)draws;
+    ok[k] = g ? 1 : 0;
+    st_after[k] = st;
+}
+
+__global__ void k_plane_hit(const rt_plane* pl, const float* org, const float* dir, const float* tmin, const float* tmax, int n, float* t_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const Ray r = make_ray(ld(org, k), ld(dir, k));
+    t_out[k] = plane_hit(ld3(pl[k].norm), ld3(pl[k].point), r, tmin[k], tmax[k]);
+}
+
 }  // namespace
 
 extern "C" {
+
+void PROBE(rtProbeShadowRay)(const rt_sphere* light, const rt_vec3* lightColor, const float* org3, const float* atten3, const float* normal3,
+                             const uint32_t* states, int n, float* out9, int* generated, uint32_t* st_after) {
+    auto a = in(org3, (size_t)3 * n); auto b = in(atten3, (size_t)3 * n); auto c = in(normal3, (size_t)3 * n); auto d = in(states, n);
+    auto e = outb(out9, (size_t)9 * n); auto f = outb(generated, n); auto g = outb(st_after, n);
+    hipLaunchKernelGGL(k_shadow_ray, grid_for(n), dim3(256), 0, 0, *light, *lightColor, a.d, b.d, c.d, d.d, n, e.d, f.d, g.d);
+    sync();
+}
+
+void PROBE(rtProbePlaneHit)(const rt_plane* planes, const float* org3, const float* dir3, const float* tmin, const float* tmax, int n, float* t_out) {
+    auto a = in(planes, n); auto b = in(org3, (size_t)3 * n); auto c = in(dir3, (size_t)3 * n); auto d = in(tmin, n); auto e = in(tmax, n);
+    auto f = outb(t_out, n);
+    hipLaunchKernelGGL(k_plane_hit, grid_for(n), dim3(256), 0, 0, a.d, b.d, c.d, d.d, e.d, n, f.d);
+    sync();
+}
 
 void PROBE(rtProbeRng)(const uint32_t* pixel_ids, int n, uint32_t* seed_out, float* draws4_out, uint32_t* state_out) {
     auto a = in(pixel_ids, n); auto b = outb(seed_out, n); auto c = outb(draws4_out, (size_t)4 * n); auto d = outb(state_out, n);

@@ -17,6 +17,9 @@
  *   rtProbeBbox         hit_bbox_dist, hit_bbox               intersections.h:7-41
  *   rtProbeScatter      material_scatter (3 BSDFs + presets)  scene_materials.h:13-93; material.h:9-143 (p3 = hit point)
  *   rtProbeMath         a/b, sqrt|a|, pow(a,5), unit_vector   vec3.h:79-81,35,194-196; material.h:12
+ *   rtProbeShadowRay    generateShadowRay as a whole          kernels.cu:363-393 (out9 = shadowDir, lightContribution, lightDist,
+ *                                                             cosAMax, number of draws consumed; generated = its bool result)
+ *   rtProbePlaneHit     planeHit                              intersections.h:43-52
  */
 #ifndef RT_PROBE_H
 #define RT_PROBE_H
@@ -42,7 +45,10 @@ void rtProbeBbox##sfx(const float* bmin3, const float* bmax3, const float* org3,
 void rtProbeScatter##sfx(const float* t, const float* p3, const float* normal3, const int* inside, const float* wo3, const rt_material* mats, \
                          const float* color3, const uint32_t* states, int n, \
                          float* wi3, float* throughput3, int* flags, float* t_out, uint32_t* st_after); \
-void rtProbeMath##sfx(const float* a, const float* b, int n, float* quot, float* root, float* p5, float* unit3);
+void rtProbeMath##sfx(const float* a, const float* b, int n, float* quot, float* root, float* p5, float* unit3); \
+void rtProbeShadowRay##sfx(const rt_sphere* light, const rt_vec3* lightColor, const float* org3, const float* atten3, const float* normal3, \
+                           const uint32_t* states, int n, float* out9, int* generated, uint32_t* st_after); \
+void rtProbePlaneHit##sfx(const rt_plane* planes, const float* org3, const float* dir3, const float* tmin, const float* tmax, int n, float* t_out);
 
 RT_PROBE_DECL(_parity)
 RT_PROBE_DECL(_fast)

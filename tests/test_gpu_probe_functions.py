@@ -220,3 +220,67 @@ def test_dormant_presets_on_device(rt, O, probe):
     assert np.allclose(wi[loose], g["wi"][loose], rtol=4e-6, atol=1e-7)
     assert np.allclose(thr[loose], g["throughput"][loose], rtol=4e-6, atol=1e-7)
     assert np.allclose(tout[loose], g["t_out"][loose], rtol=4e-6, atol=1e-7)
+
+
+def _ulp_diff(a, b):
+    """distance in units in the last place between float32 arrays of equal sign (monotone integer view)"""
+    ia = _bits(a).astype(np.int64); ib = _bits(b).astype(np.int64)
+    ia = np.where(ia & 0x80000000, 0x80000000 - ia, ia); ib = np.where(ib & 0x80000000, 0x80000000 - ib, ib)
+    return np.abs(ia - ib)
+
+
+def test_generate_shadow_ray(rt, probe, O):
+    """generateShadowRay as a whole (kernels.cu:363-393) on tabulated (origin, attenuation, normal, rng): cosAMax, the
+    generated / rejected decision, the number of draws, lightDist and the RNG state EXACT; shadowDir and lightContribution
+    within 2 ulp (of the vector's largest component) - the only inexact inputs are cosf/sinf of phi (OCML on the device, glibc in
+    the oracle).  A rejection (dotl <= 0) may legitimately flip only when |dotl| is within that error of zero."""
+    rng = np.random.default_rng(15)
+    opt = O.default_options(False)
+    lc = np.array(opt.light.center.e[:], np.float64)
+    org = (rng.uniform(-300, 300, (N, 3)) + (0, 100, 0)).astype(np.float32)
+    org[::10] = (lc + rng.normal(size=(N // 10, 3)) * 20.0).astype(np.float32)        # inside the light: cosAMax = NaN, no draws
+    att = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    nrm = rng.normal(size=(N, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    to_l = lc - org; to_l /= np.linalg.norm(to_l, axis=1, keepdims=True)
+    nrm[::3] = to_l[::3]
+    nrm = nrm.astype(np.float32)
+    seeds = (rng.integers(1, 2 ** 32, N, dtype=np.uint64) | 1).astype(np.uint32)
+    ok, sdir, lcon, dist, cam, draws, sa = probe.shadow_ray(opt.light, opt.lightColor, org, att, nrm, seeds)
+    flips = 0
+    n_gen = n_nan = n_rej = 0
+    for k in range(N):
+        e_ok, e_dir, e_con, e_dist, e_cam, e_draws, e_st = O.generate_shadow_ray(opt, org[k], att[k], nrm[k], int(seeds[k]), "orc")
+        assert _bits(cam[k]) == _bits(e_cam), k                       # cosAMax exact (NaN included)
+        assert draws[k] == e_draws and sa[k] == e_st, k              # draw count and stream position exact
+        if e_draws == 0:
+            n_nan += 1
+            assert ok[k] == 0 and e_ok == 0
+            continue
+        if ok[k] != e_ok:                                             # dotl within rounding of zero only
+            flips += 1
+            continue
+        if e_ok:
+            n_gen += 1
+            assert _bits(dist[k]) == _bits(e_dist), k                 # lightDist exact
+            assert _ulp_diff(sdir[k], e_dir).max() <= 2 or np.abs(sdir[k] - e_dir).max() <= 2.4e-7 * np.abs(e_dir).max(), k
+            assert np.abs(lcon[k] - e_con).max() <= 4e-7 * np.abs(e_con).max() + 1e-12, k      # dotl inherits the cos/sin error
+        else:
+            n_rej += 1
+    assert n_gen > 500 and n_nan > 100 and n_rej > 100 and flips <= 1, (n_gen, n_nan, n_rej, flips)
+
+
+def test_plane_hit(rt, probe, lib):
+    rng = np.random.default_rng(16)
+    pl = np.zeros((N, 6), np.float32)
+    nrm = rng.normal(size=(N, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[:500] = (0, 1, 0)
+    pl[:, 0:3] = nrm; pl[:, 3:6] = rng.uniform(-2, 2, (N, 3))
+    org, d = _rays(rng, N)
+    d[:100, 1] = 0.0                                                  # parallel to the y = const planes: denom = 0 -> miss
+    tmin = np.full(N, 0.01, np.float32); tmax = np.full(N, np.finfo(np.float32).max, np.float32); tmax[1000:1500] = rng.uniform(0.1, 3, 500)
+    t = probe.plane_hit(pl, org, d, tmin, tmax)
+    for k in range(N):
+        p = rt.plane(); p.norm.e[:] = pl[k, 0:3]; p.point.e[:] = pl[k, 3:6]
+        e = lib.orc_plane_hit(C.byref(p), _f3(org[k]), _f3(d[k]), float(tmin[k]), float(tmax[k]))
+        assert np.float32(e).view(np.uint32) == t[k].view(np.uint32), k
+    assert 300 < (t < 1e30).sum() < N - 300
