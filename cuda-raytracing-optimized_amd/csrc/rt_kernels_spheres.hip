@@ -46,10 +46,12 @@ namespace {
 
 constexpr int kWavesPerWg = 8;              // 8 waves share one LDS copy of the scene (tile kernel: 8 tiles side by side, 64 x 8 pixels)
 constexpr int kThreads = 64 * kWavesPerWg;
-constexpr int kPassGroups = 16;                                  // groups per pair-list pass: at most 64 x 16 pairs
-constexpr int kCandCap = 192;                                    // candidate list of the pair scan: 64 carried + up to 128 new per round
-constexpr int kWaveScratchPairs = 64 * 32 + 64 * 8 + (64 * kPassGroups + 64) * 2;     // per wave: ray table, best-hit keys, (lane, group) pair list
-constexpr int kWaveScratch = kWaveScratchPairs + kCandCap * 4 + 16;             // + (owner, slot) candidate list and its counter
+
+constexpr int kPassGroups = 16;
+constexpr int kListCap = 64 * 16 + 64;
+constexpr int kCandCap = 192;
+constexpr int kWaveScratchPairs = 64 * 32 + 64 * 8 + (64 * kPassGroups + 64) * 2;
+constexpr int kWaveScratch = kWaveScratchPairs + kCandCap * 4 + 16;
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     const int stripe = lr / pt.stripe_rows;
@@ -88,7 +90,7 @@ __device__ __forceinline__ int sidx(int slot) { return slot + (slot >> kSphereGr
 struct SceneLds {
     const float4* sph;      // (cx, cy, cz, r*r) of slot k at index sidx(k) = k + k/16: 17 float4 per group of 16, so that
                             // lanes reading DIFFERENT groups in one ds_read_b128 fall on different banks (pair scan)
-    const float4* grp;      // 2 x n_groups: inflated AABB (lo, hi) of each group of 16 slots
+    const float4* grp;      // 2 x n_groups: AABB (lo, hi) of each group of 16 slots
     const float4* mat;      // n_padded x (r, g, b, param)
     const int*    typ;      // n_padded
     const int*    orig;     // n_padded: the caller's sphere index of each slot (INT_MAX for pad slots)
@@ -97,6 +99,7 @@ struct SceneLds {
     unsigned char* scratch; // kWavesPerWg x kWaveScratch bytes of per-wave work space (pair scan)
 };
 
+template <bool WITH_FB>
 __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigned char* smem, float** after) {
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
@@ -117,8 +120,8 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     for (int k = threadIdx.x; k < 2 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
     for (int k = threadIdx.x; k < P.n; k += kThreads) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
-    *after = s_fb;
-    unsigned char* scratch = reinterpret_cast<unsigned char*>(s_fb + kThreads * 3);
+    *after = s_fb;                                                   // WITH_FB (tile kernel): kThreads x 3 floats of framebuffer staging
+    unsigned char* scratch = reinterpret_cast<unsigned char*>(s_fb + (WITH_FB ? kThreads * 3 : 0));
     __syncthreads();
     return { s_sph, s_grp, s_mat, s_typ, s_org, s_sof, s_rad, scratch };
 }
@@ -248,29 +251,52 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
     return out;
 }
 
-// Which small-sphere groups can still give this ray a closer hit?  Slab test of the ray against the group's inflated
-// AABB; bit g = "the ray enters the box at a distance not beyond its current closest hit".  Conservative by
-// construction: the box is inflated on the host by far more than the rounding error of this test, the entry distance is
-// shrunk by 1e-5 relative + 1e-4 absolute before it is compared, and a NaN (0 * inf on a slab plane) is dropped by
-// min/max or compares false, i.e. keeps the group.  A skipped group could only have produced hits with t > closest, which the reference rejects.
-// Handles up to 32 groups per call (groups g0 .. g0+ng-1).
-__device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, f3 org, f3 inv, float closest, bool cull) {
+// ---- exact culling: the ray side of the box tests ----------------------------------------------------------------------
+// A group (or hierarchy node) may be skipped for a ray iff no sphere in it can give the reference's scan a hit with
+// t <= the ray's current closest hit.  The test is a slab test of the ray against the node's AABB, made CONSERVATIVE:
+//  * the box is widened, per ray, by a margin m that covers (a) the rounding of the reference's own fp32 discriminant
+//    b*b - a*c (intersections.h:87-91): its error is <= 21 eps |oc|^2, so the reference reports hits for rays whose line
+//    passes a sphere of radius r at a distance up to r_eff = sqrt(r^2 + K eps |oc|^2) - far from the scene that is far
+//    outside any fixed inflation (camera at 100x the scene extent).  m = r_eff - r <= min(K eps D^2 / (2 r_min),
+//    sqrt(K eps) D) with D >= |oc| for every small sphere (distance to the centre cloud's bounding sphere + its radius),
+//    K = 96 (21 for the discriminant, the rest for the position of the phantom root along the ray); and (b) the rounding of
+//    this slab test itself, <= 8 eps (|origin| + |box|) in position: k3 x (max |org| + coord_max);
+//  * the entry distance is compared with cb = (closest + 1e-4) * 1.00002 >= closest;
+//  * a NaN (0 * inf, inf - inf on a slab plane / axis-parallel ray) is dropped by min / max, i.e. ignores that axis: keeps the node.
+// Not being part of the reference's arithmetic, the test may use what is fastest: v_rcp_f32 and fused multiply-adds
+// (lo * inv - (org + m) * inv: six v_fma_f32 per box instead of twelve sub / mul).
+struct BoxRay { f3 inv, clo, chi; float cb; };
+
+__device__ __forceinline__ BoxRay make_box_ray(const RtSphereParams& P, f3 org, f3 dn, float closest) {
+    BoxRay r;
+    r.inv = F3(__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z));
+    const f3 dc = org - F3(P.cull_cx, P.cull_cy, P.cull_cz);
+    const float D = __builtin_amdgcn_sqrtf(dot(dc, dc)) * 1.000001f + P.cull_radius;
+    const float m = fminf(P.cull_k1 * D * D, P.cull_k2 * D) + P.cull_k3 * (fmaxf(fmaxf(fabsf(org.x), fabsf(org.y)), fabsf(org.z)) + P.cull_coord_max);
+    r.clo = F3((org.x + m) * r.inv.x, (org.y + m) * r.inv.y, (org.z + m) * r.inv.z);
+    r.chi = F3((org.x - m) * r.inv.x, (org.y - m) * r.inv.y, (org.z - m) * r.inv.z);
+    r.cb = (closest + 1.0e-4f) * 1.00002f;
+    return r;
+}
+
+// true = the ray may reach the box [lo - m, hi + m] at a distance <= its current closest hit
+__device__ __forceinline__ bool box_reach(float4 lo, float4 hi, const BoxRay& r) {
+    const float x0 = __builtin_fmaf(lo.x, r.inv.x, -r.clo.x), x1 = __builtin_fmaf(hi.x, r.inv.x, -r.chi.x);
+    const float y0 = __builtin_fmaf(lo.y, r.inv.y, -r.clo.y), y1 = __builtin_fmaf(hi.y, r.inv.y, -r.chi.y);
+    const float z0 = __builtin_fmaf(lo.z, r.inv.z, -r.clo.z), z1 = __builtin_fmaf(hi.z, r.inv.z, -r.chi.z);
+    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    // skip iff (t_in > t_out) || (t_out < 0) || (t_in > cb), cb >= 0
+    return !(fmaxf(t_in, 0.0f) > fminf(t_out, r.cb));
+}
+
+__device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, const BoxRay& br, bool cull) {
     if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
-    // the entry distance shrunk by 1e-5 relative + 1e-4 absolute must not exceed `closest`:  t_in * 0.99999 - 1e-4 > closest
-    // is implied by t_in > cb with cb = (closest + 1e-4) * 1.00002 >= (closest + 1e-4) / 0.99999 (hoisted out of the loop)
-    const float cb = (closest + 1.0e-4f) * 1.00002f;
     uint32_t need = 0;
-#pragma unroll 4                                                     // 4 box loads in flight (8: slower): the loop is LDS-latency bound otherwise
+#pragma unroll 4
     for (int g = 0; g < ng; g++) {
-        const float4 lo = S.grp[2 * (g0 + g)], hi = S.grp[2 * (g0 + g) + 1];      // wave-uniform address: LDS broadcast
-        const float x0 = (lo.x - org.x) * inv.x, x1 = (hi.x - org.x) * inv.x;
-        const float y0 = (lo.y - org.y) * inv.y, y1 = (hi.y - org.y) * inv.y;
-        const float z0 = (lo.z - org.z) * inv.z, z1 = (hi.z - org.z) * inv.z;
-        const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        // (t_in > t_out) || (t_out < 0) || (t_in > cb), cb >= 0, in four instructions
-        const bool skip = fmaxf(t_in, 0.0f) > fminf(t_out, cb);
-        need |= (skip ? 0u : 1u) << g;
+        const float4 lo = S.grp[2 * (g0 + g)], hi = S.grp[2 * (g0 + g) + 1];
+        need |= (box_reach(lo, hi, br) ? 1u : 0u) << g;
     }
     return need;
 }
@@ -299,7 +325,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {
 // The work a wave does is proportional to the pairs that exist, not to 64 x (union of groups): incoherent waves do not
 // pay for each other's groups, and a wave with few live rays uses all 64 lanes on them.  WAVE-LEVEL: all 64 lanes call it.
 __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, bool has_ray, bool cull,
-                                          uint32_t& groups_done, unsigned long long* tm = nullptr) {
+                                          uint32_t& groups_done, uint32_t& boxes_done, unsigned long long* tm = nullptr) {
     // tm (diagnostic instantiation only): cycles in [1] big spheres, [2] group boxes + pair list, [3] pair rounds, [4] candidates
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
@@ -373,8 +399,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         }
     }
     lap(1);
-    // v_rcp_f32 (1 ulp) is enough here: the slab test is conservative by 1e-5 relative
-    const f3 inv = F3(__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z));
+    const BoxRay br = make_box_ray(P, org, dn, bound);
 
     // The pair list is filled pass by pass (kPassGroups groups at a time); only FULL rounds of 64 pairs are processed
     // inside a pass, the remainder is carried to the front of the next pass's list, so a partial round runs once per
@@ -383,7 +408,8 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
         const int ng = min(kPassGroups, P.n_groups - g0);
         const bool last_pass = g0 + kPassGroups >= P.n_groups;
-        const uint32_t need = has_ray ? group_needs(S, g0, ng, org, inv, bound, cull) : 0u;
+        const uint32_t need = has_ray ? group_needs(S, g0, ng, br, cull) : 0u;
+        if (has_ray) boxes_done += (uint32_t)ng;
         // exclusive prefix sum of the pair counts over the wave
         const int cnt = __popc(need);
         const int incl = wave_inclusive_scan(cnt);
@@ -516,7 +542,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
     float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r at w_ray[2r], w_ray[2r + 1]
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);   // best key of ray r at w_best[r]
-    unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);  // reachable (ray << 8 | group) pairs
+    unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);  // reachable (ray << 12 | group) pairs
     const bool mine = ((live >> lane) & 1ull) != 0ull;
     const int m = (int)__popcll(live);                               // rays (wave-uniform)
     const int my_r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
@@ -554,20 +580,14 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
             } else {
                 const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
                 const float closest = __uint_as_float((uint32_t)(w_best[r] >> 32));   // FLT_MAX-or-larger bit pattern if none: keeps everything
-                const f3 inv = F3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));   // conservative test: 1 ulp is fine
-                const float4 lo = S.grp[2 * g], hi = S.grp[2 * g + 1];
-                const float x0 = (lo.x - ro.x) * inv.x, x1 = (hi.x - ro.x) * inv.x;
-                const float y0 = (lo.y - ro.y) * inv.y, y1 = (hi.y - ro.y) * inv.y;
-                const float z0 = (lo.z - ro.z) * inv.z, z1 = (hi.z - ro.z) * inv.z;
-                const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                reach = !((t_in > t_out) || (t_out < 0.0f) || (t_in * 0.99999f - 1.0e-4f > closest));
+                const BoxRay br = make_box_ray(P, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), fminf(closest, FLT_MAX));
+                reach = box_reach(S.grp[2 * g], S.grp[2 * g + 1], br);
             }
         }
         const unsigned long long rm = __ballot(reach);
         if (reach) {
             const int at = np + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
-            w_pair[at] = (unsigned short)((r << 8) | g);
+            w_pair[at] = (unsigned short)((r << 12) | g);
         }
         np += (int)__popcll(rm);
     }
@@ -578,7 +598,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
         const int w = base + lane;
         if (w < (np << kSphereGroupShift)) {
             const unsigned pr = w_pair[w >> kSphereGroupShift];
-            const int r = (int)(pr >> 8), g = (int)(pr & 0xFFu);
+            const int r = (int)(pr >> 12), g = (int)(pr & 0xFFFu);
             const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
             sparse_test_slot(P, S, (g << kSphereGroupShift) + (w & (kSphereGroup - 1)), F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, &w_best[r]);
         }
@@ -637,7 +657,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr) {
+                                           uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
@@ -649,9 +669,9 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
     lap(0);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
         // (the sparse form lists its reachable (ray, group) pairs in the wave's pair list: rays x groups must fit it)
-        if (__popcll(live) <= sparse_max && coop_below == -1 &&
-            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= 64 * kPassGroups + 64) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
-        else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
+        if (__popcll(live) <= sparse_max && coop_below == -1 && P.n_groups <= 4096 &&
+            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
+        else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
     } else {
@@ -675,7 +695,7 @@ template <bool LEGACY>
 __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSphereParams P, int coop_below, int cull) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* s_fb;
-    const SceneLds S = stage_scene(P, smem, &s_fb);                  // s_fb: kThreads x 3 floats
+    const SceneLds S = stage_scene<true>(P, smem, &s_fb);            // s_fb: kThreads x 3 floats
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -688,13 +708,13 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
     Lane L;
     L.col = F3(0, 0, 0);
     L.org = F3(0, 0, 0); L.dir = F3(0, 0, 1);
-    uint32_t nrays = 0, groups_done = 0;
+    uint32_t nrays = 0, groups_done = 0, boxes_done = 0;
     bool active = valid && (P.ns > 0);
     if (active) start_pixel(P, L, i, global_row(P.part, lr));
 
     while (__ballot(active) != 0ull) {                               // wave-uniform loop: idle lanes stay to help
         if (active) nrays++;
-        const bool done = trace_rays<LEGACY>(P, S, L, active, coop_below, cull != 0, groups_done);
+        const bool done = trace_rays<LEGACY>(P, S, L, active, coop_below, cull != 0, groups_done, boxes_done);
         if (active && done) {
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
@@ -724,6 +744,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
         atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * (unsigned long long)kSphereGroup);     // lane-parallel phase-1 tests executed
+        atomicAdd(&P.counters->box_tests, (unsigned long long)boxes_done);
     }
 }
 
@@ -739,7 +760,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
 __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSphereParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
-    const SceneLds S = stage_scene(P, smem, &unused);
+    const SceneLds S = stage_scene<false>(P, smem, &unused);
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
@@ -903,72 +924,79 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // therefore traces a ray in (almost) every iteration until the queue is empty; which lane renders which pixel is
 // irrelevant to the result because the seed is a function of the global pixel id only.
 
-template <bool LEGACY, bool DBG>
-__global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, int coop_below, uint32_t stride, int classified,
-                                                                   int cull, int boost, int chain_cfg) {
+// Template parameters (one lean instantiation per job instead of one kernel that carries every mode as run-time state:
+// the all-in-one version kept 98 SGPRs spilled to VGPR lanes):
+//   PHASE    0 = the whole pixel (or sample chunk) in one launch; 1 = first P.s_split samples, then park the pixel;
+//            2 = resume every parked pixel from its saved stream position (cost-ordered lists)
+//   CLS      work order: 0 = queue position -> pixel by a multiplicative permutation (stride 1 = tile-major);
+//            1 = the three lists of k_classify_spheres; 2 = the kCostClasses compact lists of k_order_by_cost, tiered
+//            (chain lists -> chain waves, heavy lists spread over the first fill, the rest in descending cost)
+//   CHUNKED  RT_RNG_COUNTER: a pixel's samples are independent, P.chunks work items per pixel
+//   DBG      diagnostics (RT_WAVE_DEBUG): time stamps and section timers
+// cfg: bit 0 cull; bits 8..15 extra sparse-form rays per iteration for lanes on a long chain (boost); bits 16..23 a wave takes the
+// sparse form at <= this many live rays.  chain_cfg: bits 0..7 chain waves live in every N-th workgroup; 8..11 chain waves per such
+// workgroup; 16..23 boost threshold (rays per sample); 24..27 number of chain lists.
+template <int PHASE, int CLS, bool CHUNKED, bool DBG>
+__global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
-    const SceneLds S = stage_scene(P, smem, &unused);
+    const SceneLds S = stage_scene<false>(P, smem, &unused);
 
-    const int sparse_max = boost >> 8;
-    boost &= 0xFF;
+    const bool cull = (cfg & 1) != 0;
+    const int boost = (cfg >> 8) & 0xFF;
+    const int sparse_max = (cfg >> 16) & 0xFF;
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t padded = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
-    // classified order (classified = 1: the three lists of k_classify_spheres, each `padded` apart in P.order;
-    // classified = 2: the kCostClasses compact lists of k_order_by_cost).  Queue positions walk list 0 (the long chains)
+    // classified order (CLS = 1: the three lists of k_classify_spheres, each `padded` apart in P.order;
+    // CLS = 2: the kCostClasses compact lists of k_order_by_cost).  Queue positions walk list 0 (the long chains)
     // first, then the other lists in order; inside a list the order is scattered, except the last (sky) list.
+    // Everything the refill needs about the lists lives in LDS (s_q), not in SGPRs: it is read once per refill.
+    constexpr int n_cls = CLS == 2 ? kCostClasses : (CLS == 1 ? 3 : 0);
     __shared__ uint32_t s_cls_base[kCostClasses], s_cls_pos[kCostClasses + 1], s_cls_stride[kCostClasses];
-    const int n_cls = classified == 2 ? kCostClasses : (classified == 1 ? 3 : 0);
+    __shared__ uint32_t s_q[8];       // [0] nA (chain-list pixels)  [1] n0 (heavy-list pixels)  [2] total items of the general queue  [3] spread  [4] spread_ok
     if (threadIdx.x == 0) {
         uint32_t pos = 0;
         for (int c = 0; c < n_cls; c++) {
             const uint32_t n = P.queue[4 + c];
-            s_cls_base[c] = classified == 2 ? pos : (uint32_t)c * padded;
+            s_cls_base[c] = CLS == 2 ? pos : (uint32_t)c * padded;
             s_cls_pos[c] = pos;
             s_cls_stride[c] = (c == n_cls - 1) ? 1u : coprime_stride_of(n);
             pos += n;
         }
         for (int c = n_cls; c <= kCostClasses; c++) s_cls_pos[c] = pos;
+        // CLS = 2 (tiered): lists [0, n_chain) are the chain lists, the lists up to kChainClasses + kHeavyClasses the
+        // heavy lists, the remaining ones the rest.  CLS = 1: no chain lists; list 0 is the heavy list.
+        const int n_chain = CLS == 2 ? ((chain_cfg >> 24) & 0xF) : 0;
+        const uint32_t nA = CLS == 2 ? s_cls_pos[n_chain] : 0u;
+        const uint32_t n0 = CLS == 2 ? s_cls_pos[kChainClasses + kHeavyClasses] - nA : (n_cls ? s_cls_pos[1] : 0u);   // heavy pixels
+        const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] - nA : padded;       // pixels in the general queue
+        const uint32_t n_rest = total_px - n0;
+        // lanes that draw from the general queue at t = 0: all, minus the chain waves (which start on the chain lists)
+        uint32_t spread = gridDim.x * (uint32_t)kThreads;
+        if (nA > 0u) spread -= ((gridDim.x + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u;
+        s_q[0] = nA; s_q[1] = n0; s_q[2] = total_px * (CHUNKED ? (uint32_t)P.chunks : 1u); s_q[3] = spread;
+        s_q[4] = (n0 > 0u && n0 <= spread && (spread - n0) <= n_rest) ? 1u : 0u;
     }
     __syncthreads();
-    // classified = 2 (tiered): lists [0, n_chain) are the chain lists, the lists up to kChainClasses + kHeavyClasses the
-    // heavy lists, the remaining ones the rest.  classified = 1: no chain lists; list 0 is the heavy list.
-    const bool tiered = classified == 2;
-    const int n_chain = tiered ? ((chain_cfg >> 24) & 0xF) : 0;
-    const uint32_t nA = tiered ? s_cls_pos[n_chain] : 0u;
-    const uint32_t n0 = tiered ? s_cls_pos[kChainClasses + kHeavyClasses] - nA : (n_cls ? s_cls_pos[1] : 0u);   // heavy pixels
-    const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] - nA : padded;       // pixels in the general queue
-    const uint32_t n_rest = total_px - n0;
-    const uint32_t K = (uint32_t)P.chunks;                           // work items per pixel (1 unless RT_RNG_COUNTER)
-    const uint32_t total = total_px * K;
-    // lanes that draw from the general queue at t = 0: all, minus the chain waves (which start on the chain lists)
-    uint32_t spread = gridDim.x * (uint32_t)kThreads;
-    if (nA > 0u) spread -= ((gridDim.x + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u;
-    const bool spread_ok = n0 > 0u && n0 <= spread && (spread - n0) <= n_rest;
     // Chain waves.  A lane that is not boosted advances ONE ray per wave iteration, and an iteration takes 3-4 us for <= 4
     // live lanes (sparse form) but 15-25 us for 64: a pixel handed out at time T ends near T + rays x iteration time, and
     // the longest pixels (3700 rays: 50 bounces inside glass, sample after sample) would end the frame at 60 ms.
-    // So one wave in sixteen (role 0: wave 0 of every second workgroup) serves the chain lists from their own counter
-    // (P.queue[1]), longest first, and holds at most kSparseRays pixels: it always runs the sparse form, at raised
+    // So some waves (role 0: the first waves of every N-th workgroup) serve the chain lists from their own counter
+    // (P.queue[1]), longest first, and hold at most kSparseRays pixels: they always run the sparse form, at raised
     // priority, and the longest chain is over after 15 ms.  When the chain lists are empty the wave becomes a normal wave
     // (role 2: general queue, all 64 lanes), but keeps the cap for as long as it still holds a chain pixel.
     // (Tried and dropped: half-occupied "medium" waves for the heavy lists - what they gain in the tail they lose in throughput.)
-    const uint32_t heavy_thr = (uint32_t)((chain_cfg >> 16) & 0xFF);
     int role = 2;
-    if (nA > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
-    int tier = 2;                       // tier of the lane's pixel (= role of the wave when it was fetched)
-    int pcls = kCostClasses;            // cost list the lane's pixel came from
-    // the first `chain_heavy` chain lists (the longest chains) are held `chain_heavy_cap` to a wave instead of kSparseRays:
-    // a sparse step costs ~2 us + 0.8 us per live ray, so fewer neighbours = a shorter chain
-    const int chain_heavy_cap = (chain_cfg >> 12) & 0x3, chain_heavy = (chain_cfg >> 14) & 0x3;
+    if (CLS == 2 && s_q[0] > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
+    bool tier0 = false;                 // the lane's pixel came from a chain list (fetched while the wave had role 0)
 
     Lane L;
     L.col = F3(0, 0, 0);
     L.org = F3(0, 0, 0); L.dir = F3(0, 0, 1);
     int lr = 0;                         // local row of the lane's pixel (framebuffer row)
     int chunk = 0, s_end = 0;           // the lane's work item: samples [chunk * spw, s_end) of its pixel
-    uint32_t nrays = 0, groups_done = 0;
+    uint32_t nrays = 0, groups_done = 0, boxes_done = 0;
     bool have_pixel = false;            // lane owns an unfinished pixel
     uint32_t pix_rays = 0;              // rays traced so far for the lane's current pixel
     bool exhausted = false;             // wave-uniform: the global queue is empty
@@ -996,22 +1024,22 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             if (L.s < s_end) {
                 if (now) start_sample(P, L); else need_sample = true;
             } else {
-                if (P.phase == 1) {                                  // first samples done: park the pixel (RNG state, running sum, cost)
+                if (PHASE == 1) {                                    // first samples done: park the pixel (RNG state, running sum, cost)
                     const size_t px = (size_t)lr * P.nx + L.i;
                     P.px_state[px] = make_float4(L.col.x, L.col.y, L.col.z, __uint_as_float(L.rng));
                     P.px_rays[px] = pix_rays;
-                } else if (K == 1u) {
+                } else if (!CHUNKED) {
                     const f3 out = L.col / (float)P.ns;              // kernels.cu:568
                     // one 12-byte store (global_store_dwordx3): a lane finishes its pixel on its own, so three dword
-                    // stores would be three partial-sector writes to HBM
+                    // stores would be three partial-sector writes
                     *reinterpret_cast<float3*>(fbf + ((size_t)lr * P.nx + L.i) * 3) = make_float3(out.x, out.y, out.z);
                 } else {                                             // partial sum of this chunk; k_sum_chunks adds them in order
-                    float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * K + (uint32_t)chunk) * 3;
+                    float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * (uint32_t)P.chunks + (uint32_t)chunk) * 3;
                     dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;
                 }
                 if (wdbg) {
                     dbg_maxpix = max(dbg_maxpix, pix_rays);
-                    if (P.phase == 2)                                // per-pixel time line: (grabbed, finished) in ms, rays in total, rays in phase 1
+                    if (PHASE == 2)                                  // per-pixel time line: (grabbed, finished) in ms, rays in total, rays in phase 1
                         P.px_state[(size_t)lr * P.nx + L.i] = make_float4(dbg_grab, (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f, (float)pix_rays, dbg_p1);
                 }
                 have_pixel = false;
@@ -1025,24 +1053,22 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         while (!exhausted) {
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
-            const bool hold0 = __ballot(have_pixel && tier == 0) != 0ull;
-            const bool hold_heavy = __ballot(have_pixel && tier == 0 && pcls < chain_heavy) != 0ull;
             int cap = 64;
-            if (role == 0 || hold0) cap = (chain_heavy_cap > 0 && (hold_heavy || !hold0)) ? chain_heavy_cap : kSparseRays;
+            if (CLS == 2 && (role == 0 || __ballot(have_pixel && tier0) != 0ull)) cap = kSparseRays;
             const int allowed = cap - (int)__popcll(live_m);
             if (allowed <= 0) break;
             const unsigned long long idle_m = ~live_m;
             const uint32_t idle_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
             const unsigned long long need = __ballot(!have_pixel && idle_rank < (uint32_t)allowed);
             if (need == 0ull) break;
-            // Whole pixels (K == 1): reserve exactly as many as there are idle lanes, so nothing is hoarded in a wave while
-            // other waves idle.  Sample chunks (K > 1, counter RNG): items are small and plentiful, one atomic per idle
-            // lane-group would saturate the counter, so a wave reserves 128 at a time into a wave-local pool.
+            // Whole pixels: reserve exactly as many as there are idle lanes, so nothing is hoarded in a wave while
+            // other waves idle.  Sample chunks (counter RNG) and the 960 k two-sample items of phase 1 are small and plentiful,
+            // one atomic per idle lane-group would serialise on the counter, so a wave reserves 128 at a time into a wave-local pool.
             const uint32_t cnt = (uint32_t)__popcll(need);
+            const uint32_t total = s_q[2];
             if (pool_next >= pool_end) {
-                // (phase 1 hands out 960 k two-sample items in a millisecond: pooled too, or the one counter serialises)
-                const uint32_t grab = (K > 1u || P.phase == 1) ? max(cnt, 128u) : cnt;
-                const uint32_t limit = role == 0 ? nA : total;
+                const uint32_t grab = (CHUNKED || PHASE == 1) ? max(cnt, 128u) : cnt;
+                const uint32_t limit = role == 0 ? s_q[0] : total;
                 uint32_t b = 0;
                 if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : 0), grab);
                 b = __builtin_amdgcn_readfirstlane(b);
@@ -1060,22 +1086,24 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (role == 2 && pool_next >= total) exhausted = true;   // this grab took the last items
             if (!have_pixel && rank < take) {
-                // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
-                // neighbouring pixels over different waves, so the few very long pixels (paths trapped inside
-                // glass for 50 bounces, clustered on sphere rims) never share a wave; stride 1 = tile-major order
                 const uint32_t item = base + rank;
-                const uint32_t pos = item / K;                       // position in the pixel order; the K chunks of a pixel are adjacent items
-                chunk = (int)(item - pos * K);
+                uint32_t pos = item;                                 // position in the pixel order; the chunks of a pixel are adjacent items
+                if (CHUNKED) { pos = item / (uint32_t)P.chunks; chunk = (int)(item - pos * (uint32_t)P.chunks); }
                 uint32_t p;
-                int grab_cls = kCostClasses;
-                if (!classified) p = (uint32_t)(((unsigned long long)pos * stride) % padded);
-                else {
+                if (CLS == 0) {
+                    // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
+                    // neighbouring pixels over different waves, so the few very long pixels (paths trapped inside
+                    // glass for 50 bounces, clustered on sphere rims) never share a wave; stride 1 = tile-major order
+                    p = (uint32_t)(((unsigned long long)pos * stride) % padded);
+                } else {
                     // the n0 pixels of the heavy lists are spread evenly over the first `spread` queue positions (= the lanes in
                     // flight at t = 0), so every wave starts with a few of them instead of a few waves with nothing
                     // else; position p is a heavy-list position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
                     uint32_t q;                                      // position in the concatenation of all lists
                     if (role == 0) q = pos;
                     else {
+                        const uint32_t nA = s_q[0], n0 = s_q[1], spread = s_q[3];
+                        const bool spread_ok = s_q[4] != 0u;
                         uint32_t i0, i1;
                         bool is0;
                         if (spread_ok && pos < spread) {
@@ -1090,10 +1118,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                         q = nA + (is0 ? i0 : n0 + i1);
                     }
                     int c = 0;
-                    for (int k = 1; k < kCostClasses; k++) if (q >= s_cls_pos[k]) c = k;
-                    grab_cls = c;
+                    for (int k = 1; k < n_cls; k++) if (q >= s_cls_pos[k]) c = k;
                     const uint32_t j = q - s_cls_pos[c];
-                    if (classified == 2) {
+                    if (CLS == 2) {
                         p = P.order[s_cls_base[c] + j];              // already permuted, already (row << 16 | column): k_order_by_cost
                     } else {
                         const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
@@ -1101,7 +1128,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     }
                 }
                 int i;
-                if (classified == 2) {
+                if (CLS == 2) {
                     i = (int)(p & 0xFFFFu);
                     lr = (int)(p >> 16);
                 } else {
@@ -1111,15 +1138,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     lr = ty * 8 + (int)(within >> 3);
                 }
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
-                    if (P.phase == 0) {
+                    if (PHASE == 0) {
                         s_end = min(P.ns, (chunk + 1) * P.spw);
                         init_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
-                        need_sample = true;
                         pix_rays = 0;
-                    } else if (P.phase == 1) {
+                    } else if (PHASE == 1) {
                         s_end = P.s_split;
                         init_pixel(P, L, i, global_row(P.part, lr), 0);
-                        need_sample = true;
                         pix_rays = 0;
                     } else {                                         // resume: the pixel's stream continues where phase 1 left it
                         s_end = P.ns;
@@ -1132,11 +1157,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                         L.s = P.s_split;
                         pix_rays = P.px_rays[px];
                         if (wdbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
-                        need_sample = true;
                     }
+                    need_sample = true;
                     have_pixel = true;
-                    tier = role;
-                    pcls = grab_cls;
+                    tier0 = role == 0;
                 }
             }
         }
@@ -1156,10 +1180,11 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         // per full iteration; it gets `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
         // (One call site for both: the scan is large and must not be inlined twice.)
-        const int steps = (!LEGACY && boost > 0 && __popcll(live_now) > sparse_max) ? 1 + boost : 1;
+        const int steps = (boost > 0 && __popcll(live_now) > sparse_max) ? 1 + boost : 1;
         for (int x = 0; x < steps; x++) {
             bool sel = have_pixel;
             if (x > 0) {
+                const uint32_t heavy_thr = (uint32_t)((chain_cfg >> 16) & 0xFF);
                 const bool heavy = have_pixel && pix_rays > heavy_thr * (uint32_t)(L.s - chunk * P.spw + 2);
                 const unsigned long long hm = __ballot(heavy);
                 if (hm == 0ull) break;
@@ -1173,10 +1198,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 sel = heavy && d < kSparseRays;
             }
             if (sel) { nrays++; pix_rays++; }
-            if (!LEGACY) {
-                if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            }
-            const bool done = trace_rays<LEGACY>(P, S, L, sel, coop_below, cull != 0, groups_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr);
+            if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            const bool done = trace_rays<false>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr);
             if (DBG && wdbg) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel, steps > 1);
         }
@@ -1186,6 +1209,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
         atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * (unsigned long long)kSphereGroup);     // lane-parallel phase-1 tests executed
+        atomicAdd(&P.counters->box_tests, (unsigned long long)boxes_done);
     }
     if (wdbg) atomicMax(wdbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
     if (wdbg && (threadIdx.x & 63) == 0) {
@@ -1215,50 +1239,65 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 }
 }  // namespace
 
-static size_t lds_bytes(int n_padded, int n) {
-    // spheres + group bounds + material colour + type + original index per slot, + fb staging of the tile kernel
-    return (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 32 + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
-           (size_t)((n + 3) & ~3) * 4 + (size_t)kThreads * 3 * 4 + (size_t)kWavesPerWg * kWaveScratch;
+static size_t lds_bytes(int n_padded, int n, bool with_fb) {
+    // spheres + group bounds + material colour + type / original index / radius per slot + slot_of,
+    // + fb staging (tile kernel only) + the per-wave scratch
+    return (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 32 +
+           (size_t)n_padded * 16 + (size_t)n_padded * 12 +
+           (size_t)((n + 3) & ~3) * 4 + (with_fb ? (size_t)kThreads * 3 * 4 : 0) + (size_t)kWavesPerWg * kWaveScratch;
 }
 
 #if defined(RT_MODE_PARITY)
-size_t rt_sphere_kernel_lds_bytes(int n_padded, int n, int threads) {
-    (void)threads;
-    return lds_bytes(n_padded, n);
+size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {
+    return lds_bytes(n_padded, n, false);
 }
 #endif
 
 // variant: bits 0..7   kernel: 0 = persistent waves + pixel queue (default), 1 = one tile per wave;
-//          bits 8..15  workgroups per CU of the persistent kernel (0 = default 3);
-//          bits 16..23 0 = pair-compacted scan + sparse form (default); 255 = pair-compacted scan only.  Otherwise the earlier hybrid: lane-parallel scan, switching
-//                      to the wave-cooperative scan when fewer than this many lanes of a wave have a ray
+//          bits 8..15  workgroups per CU of the persistent kernel (0 = default 2);
+//          bits 16..23 0 = pair-compacted scan + sparse form (default); 255 = pair-compacted scan only.  Otherwise the earlier hybrid (A/B, tile
+//                      kernel only): lane-parallel scan, switching to the wave-cooperative scan when fewer than this many lanes of a wave have a ray
 //                      (1 = never cooperative, 65 = always cooperative);
 //          bit  26     disable sphere-group culling (every group is scanned: the plain brute-force scan);
 //          bits 24..25 work order of the persistent kernel: 0 = two-phase, cost-ordered (reference stream; otherwise as 3),
 //                      1 = tile-major, 2 = scattered only, 3 = one launch ordered by the centre-ray pre-pass
 //                      (glass-crossing pixels first, sky last).
-hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
-    const size_t lds = lds_bytes(p.n_padded, p.n);
-    const int kind = variant & 0xFF;
-    const int cb_bits = (variant >> 16) & 0xFF;
-    const bool legacy = cb_bits != 0 && cb_bits != 255;
-    const void* kern = (kind == 1) ? (legacy ? reinterpret_cast<const void*>(k_render_spheres_tiles<true>) : reinterpret_cast<const void*>(k_render_spheres_tiles<false>))
-                                   : (legacy ? reinterpret_cast<const void*>(k_render_spheres_queue<true, false>) : reinterpret_cast<const void*>(k_render_spheres_queue<false, false>));
+template <int PHASE, int CLS, bool CHUNKED>
+static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
+    // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
+    const void* kern = q.wave_dbg ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true>)
+                                  : reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_spheres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    return hipGetLastError();
+}
+
+hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
+    int kind = variant & 0xFF;
+    const int cb_bits = (variant >> 16) & 0xFF;
+    const bool legacy = cb_bits != 0 && cb_bits != 255;
+    if (legacy) kind = 1;                       // the brute-force A/B scans live in the tile kernel only
+    const size_t lds = lds_bytes(p.n_padded, p.n, kind == 1);
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
     // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 4, 7 = off)
     const int pb = (variant >> 27) & 7;
     // bits 30..31: a wave switches to the sparse form at <= 4 / 8 / 12 / 16 live rays (0 = default)
-    const int sparse_max = 4 + 4 * ((variant >> 30) & 3);
-    const int boost = (pb == 7 ? 0 : (pb == 0 ? 4 : pb)) | (sparse_max << 8);
-    int coop_below = (variant >> 16) & 0xFF;
-    if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
-    if (coop_below == 255) coop_below = -2;    // pair-compacted scan only (A/B)
+    int sparse_max = 4 + 4 * ((variant >> 30) & 3);
+    if (cb_bits == 255) sparse_max = 0;         // pair-compacted scan only (A/B): never the sparse form
+    const int boost = (pb == 7 || cb_bits == 255) ? 0 : (pb == 0 ? 4 : pb);
     if (kind == 1) {
+        int coop_below = cb_bits;
+        if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
+        if (coop_below == 255) coop_below = -2;    // pair-compacted scan only (A/B)
+        const void* kern = legacy ? reinterpret_cast<const void*>(k_render_spheres_tiles<true>) : reinterpret_cast<const void*>(k_render_spheres_tiles<false>);
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
         if (legacy) hipLaunchKernelGGL(k_render_spheres_tiles<true>, grid, dim3(kThreads), lds, stream, p, coop_below, cull);
         else hipLaunchKernelGGL(k_render_spheres_tiles<false>, grid, dim3(kThreads), lds, stream, p, coop_below, cull);
@@ -1285,30 +1324,23 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;
         stride = (uint32_t)(cand % (unsigned long long)total_px);
     }
-    // chain waves: wave 0 of every 2nd workgroup (256 waves); lanes above 10 rays per sample are boosted; chain lists = the
-    // first kChainClasses (measured on C2: 256 waves / 10 / 3 is the optimum of a flat basin)
     // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
     // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
-    const int chain_cfg = 1 | (1 << 8) | (0 << 12) | (3 << 14) | (10 << 16) | (kChainClasses << 24);
-    auto launch_queue = [&](const RtSphereParams& q, int classified) {
-        const dim3 grid((unsigned)blocks), block(kThreads);
-        if (legacy) hipLaunchKernelGGL((k_render_spheres_queue<true, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
-        else if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<false, true>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
-        else hipLaunchKernelGGL((k_render_spheres_queue<false, false>), grid, block, lds, stream, q, coop_below, stride, classified, cull, boost, chain_cfg);
-        return hipGetLastError();
-    };
+    const int chain_cfg = 1 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
+    const int cfg = cull | (boost << 8) | (sparse_max << 16);
+    const unsigned nb = (unsigned)blocks;
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
 
     // order_mode 0 (default), reference stream, enough samples: two phases — measure the cost of every pixel on its first
-    // samples, then resume all pixels longest-first (see k_classify_by_cost).  Otherwise: one launch, optionally ordered
+    // samples, then resume all pixels longest-first (see k_order_by_cost).  Otherwise: one launch, optionally ordered
     // by the centre-ray pre-pass (k_classify_spheres: order_mode 3) or plainly scattered (2) / tile-major (1).
     const int split = 2;                                             // measured: 2 -> 24.5 ms, 4 -> 24.8, 6 -> 25.4
     if (order_mode == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8 &&
         p.nx <= 65535 && p.part.local_rows <= 65535) {                                   // list entries pack (row << 16 | column)
         RtSphereParams q = p;
         q.phase = 1; q.s_split = split;
-        e = launch_queue(q, 0);
+        e = launch_queue_kernel<1, 0, false>(q, nb, lds, stream, stride, cfg, chain_cfg);
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(p.queue, 0, 256, stream);
         if (e != hipSuccess) return e;
@@ -1317,18 +1349,24 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         q.phase = 2;
-        return launch_queue(q, 2);
+        return launch_queue_kernel<2, 2, false>(q, nb, lds, stream, stride, cfg, chain_cfg);
     }
-    int classified = 0;
+    bool classified = false;
     if ((order_mode == 0 || order_mode == 3) && p.order != nullptr) {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_spheres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_classify_spheres, dim3(cls_blocks), dim3(kThreads), lds, stream, p);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        classified = 1;
+        classified = true;
     }
-    e = launch_queue(p, classified);
+    const bool chunked = p.chunks > 1;
+    if (classified) e = chunked ? launch_queue_kernel<0, 1, true>(p, nb, lds, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 1, false>(p, nb, lds, stream, stride, cfg, chain_cfg);
+    else e = chunked ? launch_queue_kernel<0, 0, true>(p, nb, lds, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 0, false>(p, nb, lds, stream, stride, cfg, chain_cfg);
     if (e != hipSuccess) return e;
-    if (p.chunks > 1) {
+    if (chunked) {
         const size_t npx = (size_t)p.part.local_rows * p.nx;
         hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, p);
     }

@@ -44,6 +44,10 @@ struct RtSphereParams {
     int32_t n_big;              // real big spheres: slots [0, n_big)
     const float4* spheres;      // n_padded x (cx, cy, cz, radius), spatially sorted (see rt_renderer.hip build_sphere_groups)
     const float4* groups;       // 2 x n_groups: inflated AABB (lo.xyz, hi.xyz) of each group
+    // per-ray culling margin (exactness of the culling for ANY ray origin, see make_box_ray): centre and radius of the
+    // small spheres' centres, k1 = K eps / (2 r_min), k2 = sqrt(K eps), k3 = slab-test rounding per unit of coordinate,
+    // coord_max = largest |coordinate| of any group box
+    float cull_cx, cull_cy, cull_cz, cull_radius, cull_k1, cull_k2, cull_k3, cull_coord_max;
     const float4* mat_color;    // n_padded x (r, g, b, param)
     const int32_t* mat_type;    // n_padded
     const int32_t* orig;        // n_padded: caller's sphere index of the slot, INT_MAX for pad slots
@@ -95,8 +99,8 @@ struct RtMeshParams {
     unsigned long long* dbg;    // diagnostics (RT_WAVE_DEBUG): 16 phase counters summed over all waves, or nullptr
 };
 
-// LDS the sphere kernel needs for a scene of n spheres with `threads` threads per workgroup.
-size_t rt_sphere_kernel_lds_bytes(int n_padded, int n, int threads);
+// LDS the sphere kernel needs for a scene of n spheres (n_padded slots).
+size_t rt_sphere_kernel_lds_bytes(int n_padded, int n);
 
 // Each returns the hipError_t of the launch.  `variant` selects a kernel variant (0 = default).
 hipError_t rt_launch_spheres_parity(const RtSphereParams& p, int variant, hipStream_t stream);

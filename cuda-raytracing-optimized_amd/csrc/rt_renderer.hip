@@ -88,6 +88,7 @@ struct RenderContext {
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
     std::vector<float4> h_groups;       // two float4 per group of kSphereGroup slots: inflated AABB lo / hi
+    float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0;
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
     int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0, n_big = 0;
@@ -262,7 +263,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     std::vector<int> small, big;
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (int k = 0; k < n; k++) {
-        if (radii[k] > big_above || !std::isfinite(radii[k])) { big.push_back(k); continue; }
+        if ((radii[k] > big_above || !std::isfinite(radii[k])) && big.size() < 32) { big.push_back(k); continue; }   // the kernel keeps the big-sphere candidates of a ray in one 32-bit mask
         small.push_back(k);
         for (int a = 0; a < 3; a++) {
             lo[a] = std::min(lo[a], (double)spheres[k].center.e[a]);
@@ -327,12 +328,19 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
         c.h_orig[s] = k;
         c.h_slot_of[k] = s;
     }
+    // Group boxes: the tight AABB of the group's spheres, pushed out by one float on conversion.  What makes the culling EXACT is
+    // not a static inflation but the per-ray margin the kernel adds (make_box_ray): it covers (a) the rounding of the
+    // reference's own fp32 discriminant b*b - a*c, whose error grows like |org - centre|^2 - for a far camera the reference
+    // accepts "hits" of rays that geometrically miss a sphere by more than any fixed inflation - and (b) the rounding of the slab test.
+    float coord_max = 0.0f;
+    double r_min = 1e300;
     for (int g = n_big_groups; g < c.n_groups; g++) {
         double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
         int cnt = 0;
         for (int s = g * G; s < g * G + G; s++) {
             if (slots[s] < 0) continue;
             cnt++;
+            r_min = std::min(r_min, (double)radii[slots[s]]);
             for (int a = 0; a < 3; a++) {
                 blo[a] = std::min(blo[a], (double)spheres[slots[s]].center.e[a] - radii[slots[s]]);
                 bhi[a] = std::max(bhi[a], (double)spheres[slots[s]].center.e[a] + radii[slots[s]]);
@@ -340,14 +348,32 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
         }
         if (cnt == 0) continue;
         float flo[3], fhi[3];
-        for (int a = 0; a < 3; a++) {                            // inflate far beyond fp32 rounding of the slab test
-            const double m = 1e-4 * extent + 0.01 * (bhi[a] - blo[a]);
-            flo[a] = std::nextafter((float)(blo[a] - m), -INFINITY);
-            fhi[a] = std::nextafter((float)(bhi[a] + m), INFINITY);
+        for (int a = 0; a < 3; a++) {
+            flo[a] = std::nextafter((float)blo[a], -INFINITY);
+            fhi[a] = std::nextafter((float)bhi[a], INFINITY);
+            coord_max = std::max(coord_max, std::max(fabsf(flo[a]), fabsf(fhi[a])));
         }
         c.h_groups[2 * g] = make_float4(flo[0], flo[1], flo[2], 0.0f);
         c.h_groups[2 * g + 1] = make_float4(fhi[0], fhi[1], fhi[2], 0.0f);
     }
+    // per-ray margin constants
+    double cc[3] = { 0, 0, 0 }, rad = 0.0;
+    if (!small.empty()) {
+        for (int a = 0; a < 3; a++) cc[a] = 0.5 * (lo[a] + hi[a]);
+        for (int k : small) {
+            double d2 = 0.0;
+            for (int a = 0; a < 3; a++) d2 += (spheres[k].center.e[a] - cc[a]) * (spheres[k].center.e[a] - cc[a]);
+            rad = std::max(rad, std::sqrt(d2) + radii[k]);
+        }
+    } else r_min = 1.0;
+    const double K_eps = 96.0 * 5.9604645e-8;            // K x 2^-24, see make_box_ray
+    for (int a = 0; a < 3; a++) c.cull_c[a] = (float)cc[a];
+    c.cull_radius = (float)(rad * 1.000001 + 1e-30);
+    c.cull_k1 = (float)(K_eps / (2.0 * std::max(r_min, 1e-30)));
+    c.cull_k2 = (float)std::sqrt(K_eps);
+    c.cull_k3 = 16.0f * 5.9604645e-8f;
+    c.cull_coord_max = coord_max;
+    (void)extent;
 }
 
 void cleanup_impl() {
@@ -433,7 +459,7 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
     for (int k = 0; k < n; k++)
         if (materials[k].type < RT_DIFFUSE || materials[k].type >= RT_MATERIAL_TYPE_COUNT) rt_fail("initRendererSpheres: bad material type");
     build_sphere_groups(spheres, materials, n);
-    if (rt_sphere_kernel_lds_bytes(c.n_padded, n, 256) > 160 * 1024)
+    if (rt_sphere_kernel_lds_bytes(c.n_padded, n) > 160 * 1024)
         rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 2100 spheres)");
     if (c.n_groups > 256) rt_fail("initRendererSpheres: more than 256 sphere groups (the pair list stores the group in 8 bits)");
     common_init(cam, fb, nx, ny, maxDepth);
@@ -489,6 +515,8 @@ void runRenderer(int ns, int tx, int ty) {
             p.n = c.n_spheres; p.n_padded = c.n_padded; p.n_groups = c.n_groups; p.n_big_groups = c.n_big_groups; p.n_big = c.n_big;
             p.spheres = d.d_spheres; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
+            p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
+            p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max;
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
