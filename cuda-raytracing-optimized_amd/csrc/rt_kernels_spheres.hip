@@ -200,7 +200,7 @@ __device__ __forceinline__ void scan_group_broadcast(const RtSphereParams& P, co
 __device__ __forceinline__ Hit scan_lane_parallel(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, uint32_t& groups_done) {
     Hit h = { FLT_MAX, -1, 0x7fffffff };
     for (int g = 0; g < P.n_groups; g++) {
-        groups_done++;
+        groups_done += 4u;
         scan_group_broadcast(P, S, g, org, dn, a, h);
     }
     return h;
@@ -364,7 +364,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     //    (near root accepted: closest <= t1 <= bound; near root at or below t_min: the far root bounds whatever is accepted).
     float bound = FLT_MAX;
     if (has_ray) {
-        groups_done += (uint32_t)P.n_big_groups;
+        groups_done += (uint32_t)P.n_big_groups * 4u;               // in units of 4 sphere tests
         const float ra = __builtin_amdgcn_rcpf(a);
         for (int k0 = 0; k0 < P.n_big; k0 += 32) {
             uint32_t bm = 0;
@@ -422,29 +422,37 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         const int stop = last_pass ? total : (total & ~63);          // full rounds only, except in the last pass
         lap(2);
         for (int base = 0; base < stop; base += 64) {
-            const int j = base + lane;
+            // A round takes 64 pairs, one per lane, 16 sphere tests each.  The LAST round of a ray batch is partial (a batch has ~68 pairs:
+            // one full round and a handful): with <= 32 (<= 16) pairs left, every pair is shared by 2 (4) lanes, 8 (4) tests each - the
+            // round issues a half (a quarter) of the instructions instead of running 16 tests on a few lanes.
+            const int left = stop - base;                            // wave-uniform
+            const int ls = left > 32 ? 0 : (left > 16 ? 1 : 2);
+            const int spl = kSphereGroup >> ls;                      // sphere tests per lane
+            const int j = base + (lane >> ls);
             if (j < stop) {
                 const unsigned pr = w_pair[j];
                 const int owner = (int)(pr >> 8);
-                const int slot0 = (int)(pr & 0xFFu) << kSphereGroupShift;
+                const int slot0 = ((int)(pr & 0xFFu) << kSphereGroupShift) + (lane & ((1 << ls) - 1)) * spl;
                 const int sbase = sidx(slot0);
                 const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
                 const float A = ro.w;
-                groups_done++;
+                groups_done += (uint32_t)(spl >> 2);                 // in units of 4 sphere tests
                 uint32_t mask = 0;
-#pragma unroll 8
-                for (int kk = 0; kk < kSphereGroup; kk++) {          // 8 sphere loads in flight at a time keeps the kernel inside its VGPR budget
-                    const float4 sph = S.sph[sbase + kk];
-                    const float ocx = O.x - sph.x;
-                    const float ocy = O.y - sph.y;
-                    const float ocz = O.z - sph.z;
-                    const float b = ocx * D.x + ocy * D.y + ocz * D.z;
-                    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
-                    const float nd = A * c - b * b;                  // == -(b*b - a*c) bit for bit
-                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);
+                for (int k4 = 0; k4 < spl; k4 += 4) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const float4 sph = S.sph[sbase + k4 + kk];
+                        const float ocx = O.x - sph.x;
+                        const float ocy = O.y - sph.y;
+                        const float ocz = O.z - sph.z;
+                        const float b = ocx * D.x + ocy * D.y + ocz * D.z;
+                        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
+                        const float nd = A * c - b * b;              // == -(b*b - a*c) bit for bit
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);
+                    }
                 }
-                mask <<= (32 - kSphereGroup);                        // slot0 at bit 31
+                mask <<= (32 - spl);                                 // slot0 at bit 31
                 // The spheres whose discriminant is positive (0..3 of the 16, most often 0 or 1) still need the exact
                 // sphereHit tail: IEEE sqrt + divide, 60 instructions.  Resolved in place, the wave would loop max-over-lanes
                 // times with a quarter of its lanes busy; instead every lane appends its candidates to a wave-wide LDS list
@@ -546,10 +554,15 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     const bool mine = ((live >> lane) & 1ull) != 0ull;
     const int m = (int)__popcll(live);                               // rays (wave-uniform)
     const int my_r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+    float4* w_box = reinterpret_cast<float4*>(W + kWaveScratchPairs);           // the ray side of the box tests, 3 float4 per ray (<= 16 rays: the candidate list's space)
     if (mine) {
         w_ray[2 * my_r] = make_float4(org.x, org.y, org.z, a);
         w_ray[2 * my_r + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
         w_best[my_r] = ~0ull;
+        const BoxRay b = make_box_ray(P, org, dn, 0.0f);             // once per ray (margin, reciprocals), not once per (ray, group) item
+        w_box[3 * my_r] = make_float4(b.inv.x, b.inv.y, b.inv.z, 0.0f);
+        w_box[3 * my_r + 1] = make_float4(b.clo.x, b.clo.y, b.clo.z, 0.0f);
+        w_box[3 * my_r + 2] = make_float4(b.chi.x, b.chi.y, b.chi.z, 0.0f);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -578,9 +591,11 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
             if (!cull) {
                 reach = true;
             } else {
-                const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
                 const float closest = __uint_as_float((uint32_t)(w_best[r] >> 32));   // FLT_MAX-or-larger bit pattern if none: keeps everything
-                const BoxRay br = make_box_ray(P, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), fminf(closest, FLT_MAX));
+                const float4 b0 = w_box[3 * r], b1 = w_box[3 * r + 1], b2 = w_box[3 * r + 2];
+                BoxRay br;
+                br.inv = F3(b0.x, b0.y, b0.z); br.clo = F3(b1.x, b1.y, b1.z); br.chi = F3(b2.x, b2.y, b2.z);
+                br.cb = (fminf(closest, FLT_MAX) + 1.0e-4f) * 1.00002f;
                 reach = box_reach(S.grp[2 * g], S.grp[2 * g + 1], br);
             }
         }
@@ -669,7 +684,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
     lap(0);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
         // (the sparse form lists its reachable (ray, group) pairs in the wave's pair list: rays x groups must fit it)
-        if (__popcll(live) <= sparse_max && coop_below == -1 && P.n_groups <= 4096 &&
+        if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && P.n_groups <= 4096 &&
             (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
         else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
@@ -743,7 +758,7 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
-        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * (unsigned long long)kSphereGroup);     // lane-parallel phase-1 tests executed
+        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 4ull);     // lane-parallel phase-1 tests executed
         atomicAdd(&P.counters->box_tests, (unsigned long long)boxes_done);
     }
 }
@@ -1208,7 +1223,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
-        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * (unsigned long long)kSphereGroup);     // lane-parallel phase-1 tests executed
+        atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 4ull);     // lane-parallel phase-1 tests executed
         atomicAdd(&P.counters->box_tests, (unsigned long long)boxes_done);
     }
     if (wdbg) atomicMax(wdbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
