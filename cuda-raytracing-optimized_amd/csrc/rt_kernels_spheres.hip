@@ -31,6 +31,8 @@
 #include "rt_params.h"
 
 #include <float.h>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace rtd;
 
@@ -376,10 +378,13 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 const float b = ocx * dn.x + ocy * dn.y + ocz * dn.z;
                 const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
                 const float nd = a * c - b * b;                      // == -(b*b - a*c) bit for bit
-                const bool cand = nd < 0.0f;
                 const float sq = __builtin_amdgcn_sqrtf(fmaxf(-nd, 0.0f));
                 const float err = (fabsf(b) + sq) * ra * 2.0e-6f;
                 const float t1 = (-b - sq) * ra, t2 = (-b + sq) * ra;
+                // a candidate needs the exact tail only if its FAR root can lie above t_min at all: a ray that leaves the ground sphere
+                // (origin on the sphere, both roots <= ~0: every secondary ray from a ground hit) has a positive discriminant, and its
+                // exact tail - IEEE sqrt + two IEEE divides - would only find FLT_MAX.  t2 + err bounds the reference's far root from above.
+                const bool cand = nd < 0.0f && (t2 + err > t_min);
                 const float lo = t_min + err;
                 const float tb = t1 > lo ? t1 + err : (t2 > lo ? t2 + err : FLT_MAX);
                 if (cand) bound = fminf(bound, tb);
@@ -950,7 +955,7 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 //   DBG      diagnostics (RT_WAVE_DEBUG): time stamps and section timers
 // cfg: bit 0 cull; bits 8..15 extra sparse-form rays per iteration for lanes on a long chain (boost); bits 16..23 a wave takes the
 // sparse form at <= this many live rays.  chain_cfg: bits 0..7 chain waves live in every N-th workgroup; 8..11 chain waves per such
-// workgroup; 16..23 boost threshold (rays per sample); 24..27 number of chain lists.
+// workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists.
 template <int PHASE, int CLS, bool CHUNKED, bool DBG>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1069,7 +1074,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
             int cap = 64;
-            if (CLS == 2 && (role == 0 || __ballot(have_pixel && tier0) != 0ull)) cap = kSparseRays;
+            if (CLS == 2 && (role == 0 || __ballot(have_pixel && tier0) != 0ull)) cap = (chain_cfg >> 12) & 0xF;
             const int allowed = cap - (int)__popcll(live_m);
             if (allowed <= 0) break;
             const unsigned long long idle_m = ~live_m;
@@ -1298,12 +1303,12 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     if (legacy) kind = 1;                       // the brute-force A/B scans live in the tile kernel only
     const size_t lds = lds_bytes(p.n_padded, p.n, kind == 1);
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
-    // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 4, 7 = off)
+    // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
     const int pb = (variant >> 27) & 7;
     // bits 30..31: a wave switches to the sparse form at <= 4 / 8 / 12 / 16 live rays (0 = default)
     int sparse_max = 4 + 4 * ((variant >> 30) & 3);
     if (cb_bits == 255) sparse_max = 0;         // pair-compacted scan only (A/B): never the sparse form
-    const int boost = (pb == 7 || cb_bits == 255) ? 0 : (pb == 0 ? 4 : pb);
+    const int boost = (pb == 7 || cb_bits == 255) ? 0 : (pb == 0 ? 2 : pb);      // measured on C2 (round 2): threshold 8, 2 extra rays: 6300; 10 / 4 (round 1): 6190 Msamples/s
     if (kind == 1) {
         int coop_below = cb_bits;
         if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
@@ -1342,8 +1347,14 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
     // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
-    const int chain_cfg = 1 | (1 << 8) | (10 << 16) | (kChainClasses << 24);
-    const int cfg = cull | (boost << 8) | (sparse_max << 16);
+    int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
+    int cfg = cull | (boost << 8) | (sparse_max << 16);
+    if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost"
+        int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays;
+        sscanf(t, "%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f);
+        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24);
+        cfg = cull | (e2 << 8) | (sparse_max << 16);
+    }
     const unsigned nb = (unsigned)blocks;
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
 

@@ -263,7 +263,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     std::vector<int> small, big;
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (int k = 0; k < n; k++) {
-        if ((radii[k] > big_above || !std::isfinite(radii[k])) && big.size() < 32) { big.push_back(k); continue; }   // the kernel keeps the big-sphere candidates of a ray in one 32-bit mask
+        if (radii[k] > big_above || !std::isfinite(radii[k])) { big.push_back(k); continue; }
         small.push_back(k);
         for (int a = 0; a < 3; a++) {
             lo[a] = std::min(lo[a], (double)spheres[k].center.e[a]);

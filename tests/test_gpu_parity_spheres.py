@@ -382,3 +382,21 @@ def test_scene_size_limits(rt, O):
     assert r.returncode == 99 and "does not fit" in r.stderr, (r.returncode, r.stderr[-300:])
     r = subprocess.run([sys.executable, "-c", code.replace("4000", "0")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 99 and "empty scene" in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+@pytest.mark.parametrize("dist,vfov", [(300.0, 2.5), (3000.0, 0.25), (30000.0, 0.025)])
+def test_far_camera_culling_is_still_exact(rt, O, dist, vfov):
+    """Camera at 10x .. 1000x the scene extent.  Far from the scene the reference's OWN fp32 discriminant b*b - a*c
+    (intersections.h:87-91) is so inexact (error ~ eps |oc|^2) that it reports hits for rays that geometrically miss a sphere by
+    more than any fixed box inflation - the culling must keep those groups (per-ray margin, make_box_ray): bit-exact against
+    the oracle, and equal to the brute-force scan (variant bit 26), at every distance."""
+    nx, ny, ns = 96, 64, 3
+    sp, mt, _ = rt.scene_random_spheres(nx, ny)
+    d = np.array([13.0, 2.0, 3.0]); d /= np.linalg.norm(d)
+    cam = rt.make_camera(tuple(d * dist), (0, 0, 0), (0, 1, 0), vfov, nx / ny, 0.0, dist)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50, counters=True)
+    assert cnt.hits > 0.5 * nx * ny * ns                       # the scene fills the frame
+    for variant in (0, 1 << 26):
+        got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, counters=1, variant=variant)
+        assert np.array_equal(_bits(got), _bits(ref)), (variant, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert st.rays == cnt.rays
