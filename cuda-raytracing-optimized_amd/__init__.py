@@ -311,8 +311,9 @@ def scene_staircase_procedural(detail=1):
     return tris, mats
 
 
-def make_kernel_scene(host_mesh, materials, textures=()):
-    """setup_kernel_scene, /root/reference/staircase_scene.h:166-184. Returns (kernel_scene, keepalive)."""
+def make_kernel_scene(host_mesh, materials, textures=(), floor=None):
+    """setup_kernel_scene, /root/reference/staircase_scene.h:166-184. Returns (kernel_scene, keepalive).
+    floor = (norm xyz, point xyz) of kernel_scene.floor (read by the renderer only with rt_render_options.floor = 1)."""
     materials = np.ascontiguousarray(materials, dtype=material_dtype)
     ks = kernel_scene()
     ks.m = C.pointer(host_mesh.view)
@@ -328,6 +329,10 @@ def make_kernel_scene(host_mesh, materials, textures=()):
     ks.textures = tex_arr if textures else None
     ks.numTextures = len(textures)
     ks.numPrimitivesPerLeaf = host_mesh.nppl
+    if floor is not None:
+        for a in range(3):
+            ks.floor.norm.e[a] = float(floor[a])
+            ks.floor.point.e[a] = float(floor[3 + a])
     return ks, keep
 
 

@@ -301,7 +301,12 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
 }
 
 // TRAV 0: thresholded while-while (default); TRAV 1: classic while-while (all lanes descend to a leaf, then all test their leaf)
-template <int TRAV, bool DBG>
+// STATS: the reference's `#ifdef STATS` counters (kernels.cu:47-67,399-561) as device atomics - the counting instantiation only.
+// (Round 2 built and measured a form with TWO concurrent jobs per lane - the shadow ray beside the next bounce ray, both known
+// after a diffuse hit; Russian roulette and the light sample draw in the reference's order, the shadow result is added before
+// anything else: bit-exact.  One PROCESS per bounce instead of two (-31 % process steps), 33 instead of 31 lanes per node step -
+// but every node step had to select the lane's job (+28 % cycles per step): 573-590 against 609 Msamples/s.  Not kept.)
+template <int TRAV, bool DBG, bool STATS>
 __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
@@ -341,6 +346,8 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
     const bool dbg = DBG && P.dbg != nullptr;       // DBG = false: the diagnostics (and their SGPR pressure) compile away
+    auto stat = [&](int k) { if (STATS && P.counters) atomicAdd(&P.counters->ref_stats[k], 1ull); };
+    bool from_mesh = false;                         // the path's previous hit was the triangle mesh (STATS, kernels.cu:399-432)
 
     // A lane needs a new ray job in four places (new sample, new pixel, next bounce, shadow ray); job_start (ray set-up with
     // three IEEE divides + the scene-bounds test) is called at ONE place for all of them, after PROCESS and the refill:
@@ -360,7 +367,9 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
         bounce = 0;
         inside = false;
         specular = false;
+        from_mesh = false;
         nrays++;
+        stat(RT_STAT_PRIMARY);
         want_job = 1;                                               // hit(context, p, FLT_MAX, false, ...)
     };
 
@@ -372,16 +381,24 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
             bool path_done = false;
             bool next_ray = false;                                   // continue the path with a new closest-hit job
             if (!J.shadow) {
+                // ---- the result of hit(context, p, FLT_MAX, false, inters), kernels.cu:325-360
+                const bool primary = bounce == 0;
                 const float t = J.closest;
+                int obj = 0;                                         // 0 none, 1 triangle mesh, 2 floor, 3 light
+                float t_hit = t;
+                f3 normal = F3(0, 1, 0);
+                f3 albedo = F3(0, 0, 0);
+                int mtype = RT_FLOOR_DIFFUSE;                        // floor_diffuse_scatter, scene_materials.h:30-33 (kernels.cu:481-482)
+                float mparam = 0.0f;
                 if (t < FLT_MAX) {
+                    obj = 1;
                     const Tri tri = load_tri(P.tris, J.triId);       // kernels.cu:334
-                    f3 normal = unit(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
+                    normal = unit(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
                     const float w0 = 1 - J.hu - J.hv;
                     const float tcu = (J.hu * tri.tc[2] + J.hv * tri.tc[4] + w0 * tri.tc[0]);
                     const float tcv = (J.hu * tri.tc[3] + J.hv * tri.tc[5] + w0 * tri.tc[1]);
-                    if (dot(J.r.d, normal) > 0.0f) normal = -normal; // kernels.cu:354-355
                     const rt_material mat = P.materials[tri.meshID]; // kernels.cu:452-480
-                    f3 albedo;
+                    mtype = mat.type; mparam = mat.param;
                     if (mat.texId != -1) {
                         const int width = P.tex_width[mat.texId];
                         const int height = P.tex_height[mat.texId];
@@ -395,37 +412,54 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     } else {
                         albedo = ld3(mat.color);
                     }
-                    Scatter sc;
-                    material_scatter(sc, t, J.r.o + t * J.r.d, normal, inside, dir, mat.type, albedo, mat.param, rng);
-                    org = org + sc.t * dir;                          // kernels.cu:485-489
-                    dir = sc.wi;
-                    atten = atten * sc.throughput;
-                    specular = sc.specular;
-                    inside = sc.refracted ? !inside : inside;
-
-                    bool shadow_job = false;
-                    if (P.nee && !specular) {                        // generateShadowRay, kernels.cu:363-393 (rt_device.h)
-                        ShadowSample sh;
-                        if (generate_shadow_ray(lightC, lightR, ld3(P.lightColor), org, atten, normal, rng, sh)) {
-                            pend_contrib = sh.contrib;
-                            pend_dist = sh.dist;
-                            nshadow++;
-                            shadow_dir = sh.dir;
-                            want_job = 2;                            // hit(context, p, lightDist, true, ...)
-                            shadow_job = true;
-                        }
+                } else {
+                    float tp = FLT_MAX;
+                    if (P.floor_on) tp = plane_hit(ld3(P.floor.norm), ld3(P.floor.point), J.r, eps, FLT_MAX);   // kernels.cu:341-345, re-enabled by rt_render_options.floor
+                    if (tp < FLT_MAX) {
+                        obj = 2; t_hit = tp; normal = ld3(P.floor.norm);
+                    } else if (specular && sphere_hit(lightC, lightR, J.r, eps, FLT_MAX) < FLT_MAX) {           // kernels.cu:346
+                        obj = 3;
                     }
-                    if (!shadow_job) next_ray = true;                // falls through to Russian roulette below
-                } else if (specular && sphere_hit(lightC, lightR, J.r, eps, FLT_MAX) < FLT_MAX) {   // kernels.cu:346
-                    if (!P.nee) pcolor = pcolor + atten * ld3(P.lightColor);                        // kernels.cu:440-446
+                }
+                if (obj == 0) {
+                    if (primary) stat(RT_STAT_PRIMARY_NOHITS); else stat(from_mesh ? RT_STAT_SECONDARY_MESH_NOHIT : RT_STAT_SECONDARY_NOHIT);
+                    pcolor = pcolor + atten * sky_color(P.sky, dir);                                            // kernels.cu:419-425
                     path_done = true;
                 } else {
-                    pcolor = pcolor + atten * sky_color(P.sky, dir);                                // kernels.cu:419-425
-                    path_done = true;
+                    from_mesh = obj == 1;                                                                       // kernels.cu:428-432
+                    if (primary) stat(from_mesh ? RT_STAT_PRIMARY_HIT_MESH : RT_STAT_PRIMARY_NOHITS);
+                    if (obj == 3) {
+                        if (!P.nee) pcolor = pcolor + atten * ld3(P.lightColor);                                // kernels.cu:440-446
+                        path_done = true;
+                    } else {
+                        if (dot(J.r.d, normal) > 0.0f) normal = -normal;                                        // kernels.cu:354-355
+                        Scatter sc;
+                        material_scatter(sc, t_hit, J.r.o + t_hit * J.r.d, normal, inside, dir, mtype, albedo, mparam, rng);
+                        org = org + sc.t * dir;                      // kernels.cu:485-489
+                        dir = sc.wi;
+                        atten = atten * sc.throughput;
+                        specular = sc.specular;
+                        inside = sc.refracted ? !inside : inside;
+
+                        bool shadow_job = false;
+                        if (P.nee && !specular) {                    // generateShadowRay, kernels.cu:363-393 (rt_device.h)
+                            ShadowSample sh;
+                            if (generate_shadow_ray(lightC, lightR, ld3(P.lightColor), org, atten, normal, rng, sh)) {
+                                pend_contrib = sh.contrib;
+                                pend_dist = sh.dist;
+                                nshadow++;
+                                stat(RT_STAT_SHADOWS);
+                                shadow_dir = sh.dir;
+                                want_job = 2;                        // hit(context, p, lightDist, true, ...)
+                                shadow_job = true;
+                            }
+                        }
+                        if (!shadow_job) next_ray = true;            // falls through to Russian roulette below
+                    }
                 }
             } else {
                 // shadow traversal finished: hitMesh returned J.closest; "hit" means closest < lightDist (kernels.cu:331,504-510)
-                if (!(J.closest < pend_dist)) pcolor = pcolor + pend_contrib;
+                if (!(J.closest < pend_dist)) { pcolor = pcolor + pend_contrib; stat(RT_STAT_SHADOWS_NOHITS); }
                 J.shadow = false;
                 next_ray = true;
             }
@@ -433,19 +467,26 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                 if (P.rr && bounce > 3) {                            // kernels.cu:512-527
                     const float mx = max3(atten);
                     if (rnd(rng) > mx) {
+                        stat(RT_STAT_RUSSIAN_KILL);
                         path_done = true;
                     } else {
                         const float kk = 1.0f / mx;
                         atten = F3(atten.x * kk, atten.y * kk, atten.z * kk);
                     }
                 }
-                bounce++;
-                if (bounce >= P.max_depth) path_done = true;         // loop bound, kernels.cu:402
+                if (!path_done) {
+                    bounce++;
+                    if (bounce >= P.max_depth) { stat(RT_STAT_EXCEED_MAX_BOUNCE); path_done = true; }          // loop bound, kernels.cu:402,529-531
+                }
                 if (!path_done) {
                     nrays++;
+                    stat(RT_STAT_SECONDARY);                                                                    // kernels.cu:403-408
+                    if (from_mesh) stat(RT_STAT_SECONDARY_MESH);
+                    if (STATS && len(atten) < 0.01f) stat(RT_STAT_LOW_POWER);
                     want_job = 1;
                 }
             }
+            if (STATS && path_done && (isnan(pcolor.x) || isnan(pcolor.y) || isnan(pcolor.z))) stat(RT_STAT_NAN);   // kernels.cu:559-561
             if (path_done) {
                 col = col + pcolor;                                  // kernels.cu:558
                 s++;
@@ -494,6 +535,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
         if (want_job) {
             const bool sh = want_job == 2;
             job_start(P, J, org, sh ? shadow_dir : dir, eps, sh ? pend_dist : FLT_MAX, sh);
+            if (STATS && J.idx == 0) stat(sh ? RT_STAT_SHADOWS_BBOX_NOHITS : (bounce == 0 ? RT_STAT_PRIMARY_BBOX_NOHITS : RT_STAT_SECONDARY_BBOX_NOHIT));   // kernels.cu:298-301
             want_job = 0;
         }
         if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[1] += c1 - c0; c0 = c1; }
@@ -525,6 +567,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         const bool traverseRight = rightHit < J.closest;
                         const bool swap = rightHit < leftHit;
                         if (traverseLeft || traverseRight) {
+                            if (STATS) stat((traverseLeft && traverseRight) ? RT_STAT_NODES_BOTH : RT_STAT_NODES_SINGLE);   // BVH_COUNT, kernels.cu:184-191
                             J.idx = idx2 + (swap ? 1 : 0);
                             J.bitStack = (J.bitStack << 1) + ((traverseLeft && traverseRight) ? 1u : 0u);
                         } else {
@@ -671,9 +714,11 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     const bool traverseRight = rightHit < J.closest;
                     const bool swap = rightHit < leftHit;
                     if (traverseLeft && traverseRight) {
+                        stat(RT_STAT_NODES_BOTH);
                         J.idx = idx2 + (swap ? 1 : 0);
                         J.bitStack = (J.bitStack << 1) + 1;
                     } else if (traverseLeft || traverseRight) {
+                        stat(RT_STAT_NODES_SINGLE);
                         J.idx = idx2 + (swap ? 1 : 0);
                         J.bitStack = J.bitStack << 1;
                     } else {
@@ -729,10 +774,11 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     }
 }
 
+
 }  // namespace
 
 // variant: bits 0..7  0 = persistent state-machine kernel (default), 1 = first kernel (one tile per wave);
-//          bits 8..15 workgroups per CU of the persistent kernel (0 = default 5);
+//          bits 8..15 workgroups per CU of the persistent kernel (0 = default 4);
 //          bits 16..23 keep traversing while at least this many lanes have nodes left (0 = default: 24, classic 40);
 //          bits 24..25 traversal of the persistent kernel: 0 = thresholded while-while (default), 1 = classic while-while;
 //          bits 26..31 leaf threshold of the former (0 = default 16).
@@ -767,12 +813,15 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     int leaf_thr = (variant >> 26) & 0x3F;
     if (leaf_thr == 0) leaf_thr = 16;                                         // measured (pair rounds): 12 -> 447, 16 -> 467, 24 -> 430, 31 -> 409 Msamples/s
     const dim3 grid((unsigned)blocks), block(kThreads);
+    // the counting instantiation (STATS: the reference's ray statistics as device atomics) runs only when counters are asked for
     if (classic) {
-        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<1, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
-        else hipLaunchKernelGGL((k_render_mesh_queue<1, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<1, true, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<1, false, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<1, false, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
     } else {
-        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
-        else hipLaunchKernelGGL((k_render_mesh_queue<0, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<0, false, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
     }
     return hipGetLastError();
 }

@@ -94,6 +94,8 @@ struct RtMeshParams {
     float   t_min;
     rt_sphere light;
     rt_vec3 lightColor;
+    int32_t floor_on;           // rt_render_options.floor: rays that miss the mesh are tested against `floor` (kernels.cu:341-345 re-enabled)
+    rt_plane floor;             // kernel_scene.floor
     RtCounters* counters;
     uint32_t* queue;
     unsigned long long* dbg;    // diagnostics (RT_WAVE_DEBUG): 16 phase counters summed over all waves, or nullptr

@@ -98,6 +98,7 @@ struct RenderContext {
     int nppl = 0;
     int leaf_sentinels_trailing = 1;
     rt_bbox bounds;
+    rt_plane floor;                     // kernel_scene.floor (helper_structs.h:219): used when rt_render_options.floor = 1
     std::vector<rt_material> h_materials;
     std::vector<std::vector<float>> h_tex;
     std::vector<int32_t> h_tex_w, h_tex_h;
@@ -435,6 +436,7 @@ void initRenderer(const rt_kernel_scene sc, const rt_camera cam, rt_vec3** fb, i
         }
     }
     c.bounds = sc.m->bounds;
+    c.floor = sc.floor;
     c.h_materials.assign(sc.materials, sc.materials + sc.numMaterials);                        // kernels.cu:617-618
     c.h_tex.clear(); c.h_tex_w.clear(); c.h_tex_h.clear();
     for (int t = 0; t < sc.numTextures; t++) {                                                 // kernels.cu:620-645
@@ -547,6 +549,7 @@ void runRenderer(int ns, int tx, int ty) {
                 p.wave_dbg = d.d_wave_dbg;
             }
             if (c.opt.nee) rt_fail("runRenderer: next-event estimation is only defined for mesh scenes");
+            if (c.opt.floor) rt_fail("runRenderer: the floor plane is only defined for mesh scenes (kernel_scene.floor)");
             HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream)
                                              : rt_launch_spheres_parity(p, c.opt.variant, d.stream));
             launches++;
@@ -562,6 +565,8 @@ void runRenderer(int ns, int tx, int ty) {
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.nee = c.opt.nee; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.light = c.opt.light; p.lightColor = c.opt.lightColor;
+            p.floor_on = c.opt.floor ? 1 : 0; p.floor = c.floor;
+            if (c.opt.floor && (c.opt.variant & 0xFF) == 1) rt_fail("runRenderer: the floor plane is not built into the tile-per-wave A/B kernel (variant 1)");
             p.counters = c.opt.counters ? d.d_counters : nullptr;
             p.queue = d.d_queue;
             if (getenv("RT_WAVE_DEBUG")) {                           // diagnostics: phase cycle / lane counters -> file

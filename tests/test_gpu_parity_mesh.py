@@ -234,3 +234,64 @@ def test_larger_staircase_frame_bit_exact(rt, O):
     got, st = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, nee=0, counters=1)
     assert np.array_equal(_bits(got), _bits(ref)), f"{np.count_nonzero(_bits(got) != _bits(ref))} differing words"
     assert (st.rays, st.node_visits, st.prim_tests) == (cnt.rays, cnt.node_visits, cnt.prim_tests)
+
+
+def _soup_with_floor(rt, rng, n=400):
+    tris, mats = _triangle_soup(rt, rng, n)
+    return tris, mats, (0.0, 1.0, 0.0, 0.0, -3.0, 0.0)      # plane {norm, point} (helper_structs.h:165-171)
+
+
+@pytest.mark.parametrize("variant", [0, 1 << 24])
+def test_floor_plane_and_reference_stats_bit_exact(rt, O, variant):
+    """rt_render_options.floor = 1 re-enables the reference's commented-out floor call site (planeHit + floor_diffuse_scatter,
+    kernels.cu:341-345,481-482) and counters = 1 fills the reference's 18 STATS counters (kernels.cu:47-67): with NEE off every
+    operation is exact, so the frame AND every counter must equal the oracle's (which equals the reference-arithmetic twin,
+    tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(4242)
+    tris, mats, floor = _soup_with_floor(rt, rng)
+    hm = rt.HostMesh.build(tris, 5)
+    nx, ny, ns = 72, 56, 3
+    cam = rt.make_camera((4.5, 2.5, 6.0), (0, 0, 0), (0, 1, 0), 40.0, nx / ny, 0.02, 8.0)
+    for use_floor in (1, 0):
+        o = O.default_options(False)
+        o.nee = 0; o.floor = use_floor
+        ref, cnt = O.render(O.mesh_scene(hm, mats, floor=floor), cam, o, nx, ny, ns, 12, counters=True)
+        ks, keep = rt.make_kernel_scene(hm, mats, floor=floor)
+        fb = rt.initRenderer(ks, cam, nx, ny, 12, keepalive=keep)
+        oo = rt.getDefaultRenderOptions(False)
+        rt.setRenderOptions(oo, nee=0, floor=use_floor, counters=1, variant=variant)
+        rt.runRenderer(ns, 8, 8)
+        got = np.array(fb, copy=True)
+        st = rt.getRenderStats()
+        rt.cleanupRenderer()
+        assert np.array_equal(_bits(got), _bits(ref)), (use_floor, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert (st.rays, st.node_visits, st.prim_tests) == (cnt.rays, cnt.node_visits, cnt.prim_tests)
+        assert list(st.ref_stats) == list(cnt.ref_stats), (use_floor, list(zip(rt.RT_STAT_NAMES, st.ref_stats, cnt.ref_stats)))
+        if use_floor:
+            assert st.ref_stats[rt.RT_STAT_SECONDARY_NOHIT] > 0 and st.ref_stats[rt.RT_STAT_PRIMARY_NOHITS] > 0
+        assert st.ref_stats[rt.RT_STAT_PRIMARY] == nx * ny * ns and st.ref_stats[rt.RT_STAT_NODES_BOTH] + st.ref_stats[rt.RT_STAT_NODES_SINGLE] > 0
+
+
+def test_floor_and_stats_with_nee_within_tolerance(rt, O, stair):
+    """The HEAD configuration (NEE + RR) with the floor on: image within the cos/sin tolerance, shadow-ray statistics within 0.1 %."""
+    hm, mats = stair
+    nx, ny, ns = 96, 120, 2
+    cam = rt.staircase_camera(nx, ny)
+    lo = np.array(hm.view.bounds.min.e[:])
+    floor = (0.0, 1.0, 0.0, 0.0, float(lo[1]) + 30.0, 0.0)
+    o = O.default_options(False)
+    o.floor = 1
+    ref, cnt = O.render(O.mesh_scene(hm, mats, floor=floor), cam, o, nx, ny, ns, 64, counters=True)
+    ks, keep = rt.make_kernel_scene(hm, mats, floor=floor)
+    fb = rt.initRenderer(ks, cam, nx, ny, 64, keepalive=keep)
+    oo = rt.getDefaultRenderOptions(False)
+    rt.setRenderOptions(oo, floor=1, counters=1)
+    rt.runRenderer(ns, 8, 8)
+    got = np.array(fb, copy=True)
+    st = rt.getRenderStats()
+    rt.cleanupRenderer()
+    rel = np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1e-3)
+    assert rel.mean() >= 0.999, rel.mean()
+    for k in (rt.RT_STAT_PRIMARY, rt.RT_STAT_SECONDARY, rt.RT_STAT_SHADOWS, rt.RT_STAT_SHADOWS_NOHITS, rt.RT_STAT_RUSSIAN_KILL):
+        assert abs(int(st.ref_stats[k]) - int(cnt.ref_stats[k])) <= 0.002 * max(1, cnt.ref_stats[k]) + 2, rt.RT_STAT_NAMES[k]
+    assert st.ref_stats[rt.RT_STAT_SHADOWS] == st.shadow_rays > 0
