@@ -101,8 +101,12 @@ struct SceneLds {
     unsigned char* scratch; // kWavesPerWg x kWaveScratch bytes of per-wave work space (pair scan)
 };
 
-template <bool WITH_FB>
+template <bool WITH_FB, bool GLOBAL = false>
 __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigned char* smem, float** after) {
+    if (GLOBAL) {                                                    // the scene does not fit the LDS: read it where it lies (L2-resident)
+        *after = nullptr;
+        return { P.spheres, P.groups, P.mat_color, P.mat_type, P.orig, P.slot_of, P.rad, smem };
+    }
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
     float4* s_mat = s_grp + 2 * P.n_groups;
@@ -110,11 +114,9 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     int*    s_org = s_typ + P.n_padded;
     float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
     int*    s_sof = reinterpret_cast<int*>(s_rad + P.n_padded);
+    for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += kThreads) s_sph[k] = P.spheres[k];   // the image is laid out for the LDS on the host
     for (int k = threadIdx.x; k < P.n_padded; k += kThreads) {
-        float4 s = P.spheres[k];
-        s_rad[k] = s.w;
-        s.w = s.w * s.w;                                             // intersections.h:89 radius*radius
-        s_sph[sidx(k)] = s;
+        s_rad[k] = P.rad[k];
         s_mat[k] = P.mat_color[k];
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
@@ -344,7 +346,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     // exact resolution of ONE candidate (owner ray, sphere slot) by this lane: the literal sphereHit tail, merged into the
     // owner's slot with the (t, original index) key.  t_max = FLT_MAX: a root beyond the owner's current best loses the min anyway.
     auto resolve = [&](uint32_t e) {
-        const int owner = (int)(e >> 16), k = (int)(e & 0xFFFFu);
+        const int owner = (int)(e >> 24), k = (int)(e & 0xFFFFFFu);
         const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
         const float t = sphere_hit_exact(S.sph[sidx(k)], F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, t_min, FLT_MAX);
         const int o = S.orig[k];
@@ -396,7 +398,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 while (bm) {
                     const int k = __builtin_ctz(bm);
                     bm &= bm - 1u;
-                    const uint32_t e = ((uint32_t)lane << 16) | (uint32_t)(k0 + k);
+                    const uint32_t e = ((uint32_t)lane << 24) | (uint32_t)(k0 + k);
                     if (at < (uint32_t)kCandCap) w_cand[at] = e; else resolve(e);
                     at++;
                 }
@@ -410,9 +412,12 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     // inside a pass, the remainder is carried to the front of the next pass's list, so a partial round runs once per
     // ray batch instead of once per pass.  List entries hold the ABSOLUTE group index (8 bits) and the owner lane.
     int carry = 0;                                                   // wave-uniform: pairs already in the list
+    int win_base = P.n_big_groups;                                   // entries hold lane << 10 | (group - win_base): a window of 1024 groups
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
         const int ng = min(kPassGroups, P.n_groups - g0);
-        const bool last_pass = g0 + kPassGroups >= P.n_groups;
+        // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
+        const bool flush = g0 + 2 * kPassGroups - win_base > 1024;
+        const bool last_pass = g0 + kPassGroups >= P.n_groups || flush;
         const uint32_t need = has_ray ? group_needs(S, g0, ng, br, cull) : 0u;
         if (has_ray) boxes_done += (uint32_t)ng;
         // exclusive prefix sum of the pair counts over the wave
@@ -420,7 +425,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         const int incl = wave_inclusive_scan(cnt);
         const int total = carry + __builtin_amdgcn_readlane(incl, 63);
         int at = carry + incl - cnt;
-        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 8) | (g0 + __builtin_ctz(m)));
+        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 10) | (g0 - win_base + __builtin_ctz(m)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -436,8 +441,8 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             const int j = base + (lane >> ls);
             if (j < stop) {
                 const unsigned pr = w_pair[j];
-                const int owner = (int)(pr >> 8);
-                const int slot0 = ((int)(pr & 0xFFu) << kSphereGroupShift) + (lane & ((1 << ls) - 1)) * spl;
+                const int owner = (int)(pr >> 10);
+                const int slot0 = ((win_base + (int)(pr & 0x3FFu)) << kSphereGroupShift) + (lane & ((1 << ls) - 1)) * spl;
                 const int sbase = sidx(slot0);
                 const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
@@ -468,7 +473,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                     while (mask) {
                         const int lz = __clz((int)mask);
                         mask &= ~(0x80000000u >> lz);
-                        const uint32_t e = ((uint32_t)owner << 16) | (uint32_t)(slot0 + lz);
+                        const uint32_t e = ((uint32_t)owner << 24) | (uint32_t)(slot0 + lz);
                         if (at < (uint32_t)kCandCap) w_cand[at] = e; else resolve(e);      // list full (never seen on C2): in place
                         at++;
                     }
@@ -500,6 +505,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         if (lane < carry) w_pair[lane] = moved;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (flush) win_base = g0 + kPassGroups;                      // (the list is empty here)
     }
     {                                                                // the candidates left over
         uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);
@@ -956,11 +962,12 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // cfg: bit 0 cull; bits 8..15 extra sparse-form rays per iteration for lanes on a long chain (boost); bits 16..23 a wave takes the
 // sparse form at <= this many live rays.  chain_cfg: bits 0..7 chain waves live in every N-th workgroup; 8..11 chain waves per such
 // workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists.
-template <int PHASE, int CLS, bool CHUNKED, bool DBG>
+//   GLOBAL   the scene is read from global memory instead of an LDS copy (scenes beyond ~2100 spheres)
+template <int PHASE, int CLS, bool CHUNKED, bool DBG, bool GLOBAL = false>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
-    const SceneLds S = stage_scene<false>(P, smem, &unused);
+    const SceneLds S = stage_scene<false, GLOBAL>(P, smem, &unused);
 
     const bool cull = (cfg & 1) != 0;
     const int boost = (cfg >> 8) & 0xFF;
@@ -1282,6 +1289,13 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {
 //          bits 24..25 work order of the persistent kernel: 0 = two-phase, cost-ordered (reference stream; otherwise as 3),
 //                      1 = tile-major, 2 = scattered only, 3 = one launch ordered by the centre-ray pre-pass
 //                      (glass-crossing pixels first, sky last).
+template <bool CHUNKED>
+static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned blocks, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
+    const size_t lds = (size_t)kWavesPerWg * kWaveScratch;          // only the per-wave scratch: the scene stays in global memory
+    hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, true>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    return hipGetLastError();
+}
+
 template <int PHASE, int CLS, bool CHUNKED>
 static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
     // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
@@ -1301,6 +1315,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     const int cb_bits = (variant >> 16) & 0xFF;
     const bool legacy = cb_bits != 0 && cb_bits != 255;
     if (legacy) kind = 1;                       // the brute-force A/B scans live in the tile kernel only
+    if (p.global_scene) kind = 0;               // scenes beyond the LDS: the persistent kernel only
     const size_t lds = lds_bytes(p.n_padded, p.n, kind == 1);
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
     // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
@@ -1357,6 +1372,15 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     }
     const unsigned nb = (unsigned)blocks;
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
+    if (p.global_scene) {                       // single dispatch, scattered order
+        e = p.chunks > 1 ? launch_queue_kernel_global<true>(p, nb, stream, stride, cfg, chain_cfg) : launch_queue_kernel_global<false>(p, nb, stream, stride, cfg, chain_cfg);
+        if (e != hipSuccess) return e;
+        if (p.chunks > 1) {
+            const size_t npx = (size_t)p.part.local_rows * p.nx;
+            hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, p);
+        }
+        return hipGetLastError();
+    }
 
     // order_mode 0 (default), reference stream, enough samples: two phases — measure the cost of every pixel on its first
     // samples, then resume all pixels longest-first (see k_order_by_cost).  Otherwise: one launch, optionally ordered

@@ -42,7 +42,10 @@ struct RtSphereParams {
     int32_t n_groups;           // n_padded / 16
     int32_t n_big_groups;       // groups [0, n_big_groups) hold the big spheres: always scanned
     int32_t n_big;              // real big spheres: slots [0, n_big)
-    const float4* spheres;      // n_padded x (cx, cy, cz, radius), spatially sorted (see rt_renderer.hip build_sphere_groups)
+    const float4* spheres;      // the kernel's sphere image: slot k at index k + k/16 (one pad entry per group of 16: LDS banks), (cx, cy, cz, radius*radius);
+                                // n_padded + n_groups entries, spatially sorted (see rt_renderer.hip build_sphere_groups)
+    const float*  rad;          // n_padded: radius of slot k (the hit normal divides by it, intersections.h:95)
+    int32_t global_scene;       // 1 = the scene does not fit the LDS: the kernels read these arrays from global memory (L2) instead of staging them
     const float4* groups;       // 2 x n_groups: inflated AABB (lo.xyz, hi.xyz) of each group
     // per-ray culling margin (exactness of the culling for ANY ray origin, see make_box_ray): centre and radius of the
     // small spheres' centres, k1 = K eps / (2 r_min), k2 = sqrt(K eps), k3 = slab-test rounding per unit of coordinate,

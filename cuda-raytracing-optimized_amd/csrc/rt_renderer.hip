@@ -49,6 +49,7 @@ struct DeviceState {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // sphere scene
     float4* d_spheres = nullptr;
+    float* d_rad = nullptr;
     float4* d_mat_color = nullptr;
     int32_t* d_mat_type = nullptr;
     float4* d_groups = nullptr;
@@ -84,7 +85,9 @@ struct RenderContext {
     rt_vec3* h_fb = nullptr;            // pinned, nx*ny, handed to the caller
     rt_vec3* h_ext = nullptr;           // caller-owned registered framebuffer (setExternalFramebuffer), or null
     // host copies of the scene (so devices can be (re)configured by setRenderOptions)
-    std::vector<float4> h_spheres;      // padded
+    std::vector<float4> h_spheres;      // the kernel's sphere image (rt_params.h): (n_padded + n_groups) x (cx, cy, cz, r*r)
+    std::vector<float> h_rad;           // n_padded radii
+    int global_scene = 0;
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
     std::vector<float4> h_groups;       // two float4 per group of kSphereGroup slots: inflated AABB lo / hi
@@ -131,7 +134,7 @@ void free_device(DeviceState& d) {
     HIP_CHECK(hipSetDevice(d.device));
     if (d.stream) HIP_CHECK(hipStreamSynchronize(d.stream));
     auto fr = [](void* p) { if (p) HIP_CHECK(hipFree(p)); };
-    fr(d.d_spheres); fr(d.d_mat_color); fr(d.d_mat_type); fr(d.d_groups); fr(d.d_orig); fr(d.d_slot_of);
+    fr(d.d_spheres); fr(d.d_rad); fr(d.d_mat_color); fr(d.d_mat_type); fr(d.d_groups); fr(d.d_orig); fr(d.d_slot_of);
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
@@ -180,6 +183,7 @@ void setup_devices() {
         HIP_CHECK(hipEventCreate(&d.ev_stop));
         if (c.is_spheres) {
             d.d_spheres = upload(c.h_spheres);
+            d.d_rad = upload(c.h_rad);
             d.d_mat_color = upload(c.h_mat_color);
             d.d_mat_type = upload(c.h_mat_type);
             d.d_groups = upload(c.h_groups);
@@ -312,7 +316,9 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     c.n_groups = c.n_padded / G;
     c.n_big_groups = n_big_groups;
     c.n_big = (int)big.size();
-    c.h_spheres.assign(c.n_padded, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));      // pad: radius 0, far away
+    const auto sidx = [](int slot) { return slot + slot / kSphereGroup; };
+    c.h_spheres.assign(c.n_padded + c.n_groups, make_float4(0.0f, 3.0e18f, 0.0f, 0.0f));      // pad: radius 0, far away
+    c.h_rad.assign(c.n_padded, 0.0f);
     c.h_mat_color.assign(c.n_padded, make_float4(0, 0, 0, 0));
     c.h_mat_type.assign(c.n_padded, RT_DIFFUSE);
     c.h_orig.assign(c.n_padded, INT_MAX);
@@ -323,7 +329,10 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     for (int s = 0; s < c.n_padded; s++) {
         const int k = slots[s];
         if (k < 0) continue;
-        c.h_spheres[s] = make_float4(spheres[k].center.e[0], spheres[k].center.e[1], spheres[k].center.e[2], spheres[k].radius);
+        const float r = spheres[k].radius;
+        const float r2 = r * r;                                    // intersections.h:89 radius*radius: one IEEE multiply, the same bits as on the device
+        c.h_spheres[sidx(s)] = make_float4(spheres[k].center.e[0], spheres[k].center.e[1], spheres[k].center.e[2], r2);
+        c.h_rad[s] = r;
         c.h_mat_color[s] = make_float4(materials[k].color.e[0], materials[k].color.e[1], materials[k].color.e[2], materials[k].param);
         c.h_mat_type[s] = materials[k].type;
         c.h_orig[s] = k;
@@ -461,9 +470,10 @@ void initRendererSpheres(const rt_sphere* spheres, const rt_material* materials,
     for (int k = 0; k < n; k++)
         if (materials[k].type < RT_DIFFUSE || materials[k].type >= RT_MATERIAL_TYPE_COUNT) rt_fail("initRendererSpheres: bad material type");
     build_sphere_groups(spheres, materials, n);
-    if (rt_sphere_kernel_lds_bytes(c.n_padded, n) > 160 * 1024)
-        rt_fail("initRendererSpheres: scene does not fit the 160 KB LDS of a CU (about 2100 spheres)");
-    if (c.n_groups > 256) rt_fail("initRendererSpheres: more than 256 sphere groups (the pair list stores the group in 8 bits)");
+    // Scenes up to ~2100 spheres live in the LDS of every workgroup; larger ones are read from global memory (they stay in L2) by the
+    // same kernel (no cost-ordered second phase, no sparse form beyond 4096 groups: slower per ray, same image).
+    c.global_scene = rt_sphere_kernel_lds_bytes(c.n_padded, n) > 160 * 1024 ? 1 : 0;
+    if (c.n_padded > (1 << 24)) rt_fail("initRendererSpheres: more than 16 M sphere slots");
     common_init(cam, fb, nx, ny, maxDepth);
 }
 
@@ -515,7 +525,7 @@ void runRenderer(int ns, int tx, int ty) {
             memset(&p, 0, sizeof p);
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
             p.n = c.n_spheres; p.n_padded = c.n_padded; p.n_groups = c.n_groups; p.n_big_groups = c.n_big_groups; p.n_big = c.n_big;
-            p.spheres = d.d_spheres; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
+            p.spheres = d.d_spheres; p.rad = d.d_rad; p.global_scene = c.global_scene; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
             p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max;
