@@ -594,9 +594,13 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t packed = (uint32_t)J.idx | (J.shadow ? 0x80000000u : 0u);
-                        for (int base = 0; base < n_leaf; base += pair_per) {
+                        // only FULL rounds (pair_per rays x nppl triangles fill the wave); the remaining owners keep waiting at their leaf and
+                        // are served by the next leaf phase - a second round with a handful of pairs costs as much as a full one
+                        // (16 owners x 5 triangles = 64 + 16 pairs was the common case).  Fewer owners than one round: all of them.
+                        const int n_serve = n_leaf >= pair_per ? (n_leaf / pair_per) * pair_per : n_leaf;
+                        for (int base = 0; base < n_serve; base += pair_per) {
                             const int r = base + (int)pair_r;
-                            const bool pv = pair_ok && r < n_leaf;
+                            const bool pv = pair_ok && r < n_serve;
                             const uint32_t owner = pv ? w_owner[r] : lane;
                             const int src = (int)(owner << 2);
                             const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.x)));
@@ -642,12 +646,13 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         __builtin_amdgcn_wave_barrier();
                         unsigned long long my_best = ~0ull;              // owner side: result of my leaf
                         float my_u = 0.0f, my_v = 0.0f;
-                        if (at_leaf) {
+                        const bool served = at_leaf && (int)my_rank < n_serve;
+                        if (served) {
                             my_best = w_best[lane];
                             const float2 uv = w_uv[lane];
                             my_u = uv.x; my_v = uv.y;
                         }
-                        if (at_leaf) {
+                        if (served) {
                             if (my_best != ~0ull && J.shadow) {          // any-hit: hitBvh returns 0.0f (kernels.cu:205)
                                 J.closest = 0.0f;
                                 J.idx = 0;
@@ -811,7 +816,9 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     int min_traversing = (variant >> 16) & 0xFF;
     if (min_traversing == 0) min_traversing = classic ? kMinTraversing : 24;    // measured: 16 -> 409, 20 -> 435, 24 -> 446, 32 -> 429 Msamples/s
     int leaf_thr = (variant >> 26) & 0x3F;
-    if (leaf_thr == 0) leaf_thr = 16;                                         // measured (pair rounds): 12 -> 447, 16 -> 467, 24 -> 430, 31 -> 409 Msamples/s
+    // default leaf threshold = one full pair round: 64 / nppl waiting rays (12 at 5 triangles per leaf).  Measured on C4 with full rounds
+    // only: 8 -> 607, 12 -> 648, 16 -> 616, 24 -> 541 Msamples/s (round 1, with partial rounds: 16 -> 610).
+    if (leaf_thr == 0) leaf_thr = (p.nppl >= 1u && p.nppl <= 16u) ? (int)(64u / p.nppl) : 16;
     const dim3 grid((unsigned)blocks), block(kThreads);
     // the counting instantiation (STATS: the reference's ray statistics as device atomics) runs only when counters are asked for
     if (classic) {

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""tools/one_frame.py <C2|C3|C4|C5> [frames] — renders bench.py's workload of that name: one tiny warm-up frame (1 spp), then `frames`
+full frames, and nothing else.  The program rocprofv3 is wrapped around (tools/measure_traffic.sh): per-frame counters are the
+LAST frames' dispatches."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C2"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+w = bench.WORKLOADS[name]
+b = bench.HipBackend()
+b.open(w, 0, 1, None)
+b.step(1)
+ms = [b.step() for _ in range(frames)]
+b.close()
+print(json.dumps({"workload": name, "frames": frames, "kernel_ms": ms, "Msamples_per_s": w["nx"] * w["ny"] * w["spp"] / min(ms) / 1e3}))
