@@ -1385,7 +1385,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // order_mode 0 (default), reference stream, enough samples: two phases — measure the cost of every pixel on its first
     // samples, then resume all pixels longest-first (see k_order_by_cost).  Otherwise: one launch, optionally ordered
     // by the centre-ray pre-pass (k_classify_spheres: order_mode 3) or plainly scattered (2) / tile-major (1).
-    const int split = 2;                                             // measured: 2 -> 24.5 ms, 4 -> 24.8, 6 -> 25.4
+    const int split = 2;                                             // measured: 1 -> 15.5 ms, 2 -> 15.0, 3 -> 15.1 (round 2); 2 -> 24.5, 4 -> 24.8, 6 -> 25.4 (round 1)
     if (order_mode == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8 &&
         p.nx <= 65535 && p.part.local_rows <= 65535) {                                   // list entries pack (row << 16 | column)
         RtSphereParams q = p;

@@ -34,6 +34,7 @@ namespace {
 void hip_check(hipError_t result, const char* func, const char* file, int line) {   // kernels.cu:27-38
     if (result != hipSuccess) {
         fprintf(stderr, "HIP error = %s at %s:%d '%s' \n", hipGetErrorString(result), file, line, func);
+        (void)hipDeviceReset();                                     // kernels.cu:34-35: reset before exiting
         exit(99);
     }
 }
@@ -662,6 +663,9 @@ void getRenderStats(rt_render_stats* out) {
 void cleanupRenderer(void) {
     if (!g_ctx.initialised) return;
     cleanup_impl();
+    // kernels.cu:679 ends with cudaDeviceReset().  A reset destroys EVERY context of the process on that device - also the one of a
+    // host that shares the process (PyTorch in bench.py, a viewer) - so it is opt-in here: RT_CLEANUP_DEVICE_RESET=1 mirrors the reference.
+    if (const char* r = getenv("RT_CLEANUP_DEVICE_RESET")) if (r[0] == '1') (void)hipDeviceReset();
 }
 
 }  // extern "C"
