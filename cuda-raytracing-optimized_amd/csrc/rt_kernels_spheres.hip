@@ -961,7 +961,8 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 //   DBG      diagnostics (RT_WAVE_DEBUG): time stamps and section timers
 // cfg: bit 0 cull; bits 8..15 extra sparse-form rays per iteration for lanes on a long chain (boost); bits 16..23 a wave takes the
 // sparse form at <= this many live rays.  chain_cfg: bits 0..7 chain waves live in every N-th workgroup; 8..11 chain waves per such
-// workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists.
+// workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists; 28..31 pixels a
+// chain wave holds while one of them comes from list 0 (the longest chains).
 //   GLOBAL   the scene is read from global memory instead of an LDS copy (scenes beyond ~2100 spheres)
 template <int PHASE, int CLS, bool CHUNKED, bool DBG, bool GLOBAL = false>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg) {
@@ -1017,6 +1018,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     int role = 2;
     if (CLS == 2 && s_q[0] > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
     bool tier0 = false;                 // the lane's pixel came from a chain list (fetched while the wave had role 0)
+    bool long0 = false;                 // ... from list 0, the longest chains: such a wave holds fewer pixels (a sparse step costs ~2 us + 0.8 us per live ray)
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -1081,7 +1083,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
             int cap = 64;
-            if (CLS == 2 && (role == 0 || __ballot(have_pixel && tier0) != 0ull)) cap = (chain_cfg >> 12) & 0xF;
+            if (CLS == 2 && (role == 0 || __ballot(have_pixel && tier0) != 0ull))
+                cap = (__ballot(have_pixel && long0) != 0ull) ? ((chain_cfg >> 28) & 0xF) : ((chain_cfg >> 12) & 0xF);
             const int allowed = cap - (int)__popcll(live_m);
             if (allowed <= 0) break;
             const unsigned long long idle_m = ~live_m;
@@ -1188,6 +1191,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     need_sample = true;
                     have_pixel = true;
                     tier0 = role == 0;
+                    long0 = CLS == 2 && role == 0 && pos < s_cls_pos[1];
                 }
             }
         }
@@ -1362,12 +1366,12 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
     // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
-    int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
+    int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24) | (2 << 28);
     int cfg = cull | (boost << 8) | (sparse_max << 16);
     if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost"
-        int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays;
-        sscanf(t, "%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f);
-        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24);
+        int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 2;
+        sscanf(t, "%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g);
+        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24) | (g << 28);
         cfg = cull | (e2 << 8) | (sparse_max << 16);
     }
     const unsigned nb = (unsigned)blocks;
