@@ -246,11 +246,15 @@ def mesh_roofline(job, world, traffic=None):
 # ------------------------------------------------------------------------------------------------------
 
 def kernel_source_hash():
+    """Hash of the CODE of the kernel sources (// comments and blank space do not count)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cuda-raytracing-optimized_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+            txt = open(os.path.join(d, f), encoding="utf-8", errors="replace").read()
+            code = "\n".join(ln for ln in (re.sub(r"\s+", " ", re.sub(r"//.*", "", ln)).strip() for ln in txt.splitlines()) if ln)
+            h.update(f.encode()); h.update(code.encode())
     return h.hexdigest()[:16]
 
 

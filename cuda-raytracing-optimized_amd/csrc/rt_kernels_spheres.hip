@@ -22,11 +22,15 @@
 //     candidates are visited in increasing index with the same strict `<`, the result is
 //     bit-identical to the reference's linear scan;
 //   * sphere-group culling + pair compaction (scan_pairs): the host splits the small spheres at medians
-//     into compact groups of 16 with an inflated AABB each; a ray only visits the groups whose box it enters before its
-//     current closest hit, and the (ray, group) pairs of a wave are compacted so that all 64 lanes always work.
+//     into compact groups of 16 with a tight AABB each; a ray only visits the groups whose box it can reach before its
+//     current closest hit (slab test widened by a per-ray margin that covers the reference's own discriminant rounding:
+//     exact for any ray origin), and the (ray, group) pairs of a wave are compacted so that all 64 lanes always work.
 //     A skipped sphere could only have produced t > closest (rejected by the reference) or FLT_MAX, so the result
 //     is unchanged; the explicit (t, original index) tie rule keeps the reference's first-index-wins order;
-//   * framebuffer stores go through an LDS transpose so a wave writes row-contiguous dwords.
+//   * framebuffer: the persistent kernels (default) store a finished pixel with ONE 12-byte store from the lane that owns it
+//     (pixels finish one by one, in cost order); only the tile kernel (variant 1) transposes its 8x8 tile through LDS so that a
+//     wave writes row-contiguous dwords;
+//   * scenes that do not fit the LDS (> ~2100 spheres) are read from global memory by the same kernel (template flag GLOBAL).
 #include "rt_device.h"
 #include "rt_params.h"
 

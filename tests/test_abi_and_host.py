@@ -180,3 +180,33 @@ def test_output_harness(rt, tmp_path):
     exp = np.sqrt(((fb.astype(np.float64) - g.astype(np.float64)) ** 2 / 3.0).sum() / 30)
     assert abs(rt.rmse(fb, g) - exp) < 1e-7
     assert rt.rmse(fb, fb) == 0.0
+
+
+def test_bench_reports_traffic_only_for_the_kernel_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, tools/measure_traffic.sh), which
+    records the hash of the kernel sources it was taken on: a changed kernel must not inherit a stale figure."""
+    import json
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: h)
+    assert bench.committed_traffic("C2", 100.0)["traffic"] is None                     # no file
+    json.dump({"kernel_source_hash": h, "C2": {"bytes_per_frame": 300.0}}, open(prof / "traffic.json", "w"))
+    t = bench.committed_traffic("C2", 100.0)
+    assert t["traffic"] == 300.0 and t["traffic_over_algorithmic"] == 3.0 and "committed_profile" in t["traffic_source"]
+    assert bench.committed_traffic("C4", 100.0)["traffic"] is None                     # no entry for that config
+    json.dump({"kernel_source_hash": "0" * 16, "C2": {"bytes_per_frame": 300.0}}, open(prof / "traffic.json", "w"))
+    assert bench.committed_traffic("C2", 100.0)["traffic"] is None                     # other kernel sources
+
+
+def test_committed_traffic_matches_the_committed_kernel_sources():
+    """profiles/traffic.json must have been measured on the kernel sources in this checkout (else bench.py prints traffic: null)."""
+    import json
+    import bench
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        pytest.skip("no committed traffic measurement")
+    assert json.load(open(p))["kernel_source_hash"] == bench.kernel_source_hash()
