@@ -283,6 +283,17 @@ __device__ __forceinline__ float hit_bbox_dist(f3 bmin, f3 bmax, const Ray& r, f
     return (t_max < t_min) ? FLT_MAX : t_min;
 }
 
+// The same test with the two results apart: `hit` = the slabs overlap, t_entry = the entry distance (hit_bbox_dist returns
+// hit ? t_entry : FLT_MAX).  For callers that only compare the result (`< closest`, `right < left`): the compares fold into mask logic.
+__device__ __forceinline__ bool hit_bbox_entry(f3 bmin, f3 bmax, const Ray& r, float t_max, float& t_entry) {
+    float t_min = 0.001f;
+    slab(bmin.x, bmax.x, r.o.x, r.inv.x, t_min, t_max);
+    slab(bmin.y, bmax.y, r.o.y, r.inv.y, t_min, t_max);
+    slab(bmin.z, bmax.z, r.o.z, r.inv.z, t_min, t_max);
+    t_entry = t_min;
+    return !(t_max < t_min);
+}
+
 // The early-out of the reference matters for ONE thing: a NaN produced on a later axis (0 * inf)
 // can only appear after an earlier axis already failed... it cannot un-fail the test, because NaN
 // compares false and leaves t_min/t_max unchanged.  So the branch-free form is exact.

@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
     const bool dbg = DBG && P.dbg != nullptr;       // DBG = false: the diagnostics (and their SGPR pressure) compile away
+    constexpr bool COUNT = STATS || DBG;            // ray / node / triangle counters: only the instantiations launched when counters are asked for
     auto stat = [&](int k) { if (STATS && P.counters) atomicAdd(&P.counters->ref_stats[k], 1ull); };
     bool from_mesh = false;                         // the path's previous hit was the triangle mesh (STATS, kernels.cu:399-432)
 
@@ -549,23 +550,40 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
             // because descents between two leaves take 1..30 steps.  Here the leaf loop runs as soon as `leaf_thr` lanes
             // wait at a leaf (or no lane is at a node): lanes waiting for the slowest descent are capped at leaf_thr.
             // Every ray still sees the reference's own sequence of node visits and triangle tests.
-            do {
-                const bool act = have_pixel && J.idx != 0;
-                const bool at_node = act && (uint32_t)J.idx < P.first_leaf;
-                const int n_node = (int)__popcll(__ballot(at_node));
-                const int n_leaf = (int)__popcll(__ballot(act && !at_node));
-                if (n_node > 0 && n_leaf < leaf_thr) {
+            // A lane without a pixel has J.idx == 0 (a pixel ends in PROCESS, where J.idx is 0, and nothing starts a job for it), so the
+            // lane masks of a step are two compares of J.idx; `have_pixel` does not change inside the loop.
+            const int n_have = (int)__popcll(__builtin_amdgcn_ballot_w64(have_pixel));
+            bool first = true;
+            for (;;) {
+                // ---- node steps (kernels.cu:162-195) for the lanes at an internal node, until the leaf phase is due or the loop is left
+                unsigned long long act_m, node_m;
+                bool leave = false;
+                int n_leaf = 0;
+                for (;;) {
+                    act_m = __builtin_amdgcn_ballot_w64(J.idx != 0);
+                    // back to PROCESS when enough lanes have a finished traversal to consume (or nothing is left to traverse); at least one
+                    // step; lanes without a pixel (end of the frame) do not count, so the tail does not bounce between the phases
+                    if (act_m == 0ull || (!first && n_have - (int)__popcll(act_m) >= 64 - min_traversing)) { leave = true; break; }
+                    first = false;
+                    node_m = act_m & __builtin_amdgcn_ballot_w64((uint32_t)J.idx < P.first_leaf);
+                    const int n_node = (int)__popcll(node_m);
+                    n_leaf = (int)__popcll(act_m & ~node_m);
+                    if (n_node == 0 || n_leaf >= leaf_thr) break;
                     if (dbg) { g_act[2] += (unsigned long long)n_node; g_it[2]++; }
+                    const bool at_node = J.idx != 0 && (uint32_t)J.idx < P.first_leaf;
                     if (at_node) {
                         const int idx2 = J.idx << 1;
                         const float4* n = P.bvh4 + (size_t)J.idx * 3;
                         const float4 na = n[0], nb = n[1], nc = n[2];
-                        st.nodes++;
-                        const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest);
-                        const bool traverseLeft = leftHit < J.closest;
-                        const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest);
-                        const bool traverseRight = rightHit < J.closest;
-                        const bool swap = rightHit < leftHit;
+                        if (COUNT) st.nodes++;
+                        // leftHit / rightHit of kernels.cu:175-181 are (hit ? entry : FLT_MAX); only compared, so kept as (hit, entry):
+                        // `x < closest` = hit && entry < closest (closest <= FLT_MAX), `rightHit < leftHit` = as below when one side is taken
+                        float le, re;
+                        const bool hl = hit_bbox_entry(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest, le);
+                        const bool hr = hit_bbox_entry(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest, re);
+                        const bool traverseLeft = hl && le < J.closest;
+                        const bool traverseRight = hr && re < J.closest;
+                        const bool swap = traverseRight && (!traverseLeft || re < le);
                         if (traverseLeft || traverseRight) {
                             if (STATS) stat((traverseLeft && traverseRight) ? RT_STAT_NODES_BOTH : RT_STAT_NODES_SINGLE);   // BVH_COUNT, kernels.cu:184-191
                             J.idx = idx2 + (swap ? 1 : 0);
@@ -577,7 +595,11 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         }
                     }
                     if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[2] += c1 - c0; c0 = c1; }
-                } else {
+                }
+                if (leave) break;
+                const bool act = J.idx != 0;
+                const bool at_node = act && (uint32_t)J.idx < P.first_leaf;
+                {
                     if (dbg) { g_act[3] += (unsigned long long)n_leaf; g_it[3]++; }
                     if (pair_per > 0) {
                         // (ray, triangle) pairs: the <= leaf_thr lanes at a leaf have nppl triangles each; tested one triangle
@@ -588,7 +610,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         // (its running t_max only rejects what the minimum rejects too); a shadow ray stops at the FIRST k that
                         // hits.  Both are what min(key) below is, key = t_bits << 32 | k (t > 0) resp. k for shadow rays.
                         const bool at_leaf = act && !at_node;
-                        const unsigned long long leaf_m = __ballot(at_leaf);
+                        const unsigned long long leaf_m = act_m & ~node_m;
                         const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(leaf_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)leaf_m, 0u));
                         if (at_leaf) { w_owner[my_rank] = lane; w_best[lane] = ~0ull; }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -638,7 +660,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                             if (pv) {
                                 const unsigned long long best = w_best[owner];
                                 // tests the reference executes: every reached triangle; a shadow ray stops after its first hit
-                                if (reached && (!o_shadow || best == ~0ull || (unsigned long long)pair_k <= best)) st.tests++;
+                                if (COUNT && reached && (!o_shadow || best == ~0ull || (unsigned long long)pair_k <= best)) st.tests++;
                                 if (hit && key == best) w_uv[owner] = make_float2(u, v);
                             }
                         }
@@ -677,7 +699,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                             if (isinf(a.x)) break;                       // kernels.cu:202 sentinel
                             const float cx = pt[2].x;
                             float u, v;
-                            st.tests++;
+                            if (COUNT) st.tests++;
                             const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
                             if (hitT < J.closest) {
                                 if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
@@ -697,9 +719,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     }
                     if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[3] += c1 - c0; c0 = c1; }
                 }
-                // back to PROCESS when enough lanes have a finished traversal to consume (or nothing is left to traverse);
-                // lanes without a pixel (end of the frame) do not count, so the tail does not bounce between the phases
-            } while (__ballot(have_pixel && J.idx != 0) != 0ull && (int)__popcll(__ballot(have_pixel && J.idx == 0)) < 64 - min_traversing);
+            }
         } else {
             do {
                 // descend: internal nodes (kernels.cu:162-195)

@@ -13,7 +13,10 @@ ap.add_argument("--spp", type=int, default=256); ap.add_argument("--depth", type
 ap.add_argument("--detail", type=int, default=4); ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--fp", default="parity"); ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--count-spp", type=int, default=4)
+ap.add_argument("--lib", default=None, help="an experimental build of librt_mi355x.so (tools only)")
 a = ap.parse_args()
+if a.lib:
+    rt.RENDERER_LIB = os.path.abspath(a.lib)
 t0 = time.time()
 tris, mats = rt.scene_staircase_procedural(a.detail)
 hm = rt.HostMesh.build(tris, 5)
