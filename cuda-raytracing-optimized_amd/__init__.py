@@ -131,7 +131,7 @@ RENDERER_SYMBOLS = ["initRenderer", "runRenderer", "cleanupRenderer", "initRende
                     "getDefaultRenderOptions", "setRenderOptions", "setExternalFramebuffer", "getRenderStats",
                     "rtDeviceCount", "rtApiVersion"]
 HOST_SYMBOLS = ["rtMakeCamera", "rtRandomFloat", "rtSceneThreeSpheres", "rtSceneRandomSpheres", "rtStaircaseCamera",
-                "rtBuildBvh", "rtLoadBvhFile", "rtSaveBvhFile", "rtFreeMesh", "rtMeshView",
+                "rtBuildBvh", "rtBuildBvhLevels", "rtLoadBvhFile", "rtSaveBvhFile", "rtFreeMesh", "rtMeshView",
                 "rtSceneStaircaseProcedural", "rtLinearToSRGB", "rtWritePPM", "rtSaveReference", "rtLoadReference", "rtRmse"]
 
 _renderer = None
@@ -158,6 +158,8 @@ def load_host():
         h.rtStaircaseCamera.restype = None
         h.rtBuildBvh.argtypes = [C.c_void_p, C.c_int, C.c_int]
         h.rtBuildBvh.restype = C.c_void_p
+        h.rtBuildBvhLevels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        h.rtBuildBvhLevels.restype = C.c_void_p
         h.rtLoadBvhFile.argtypes = [C.c_char_p]
         h.rtLoadBvhFile.restype = C.c_void_p
         h.rtSaveBvhFile.argtypes = [C.c_void_p, C.c_char_p]
@@ -268,9 +270,12 @@ class HostMesh:
         self.nppl = load_host().rtMeshView(self._h, C.byref(self.view))
 
     @classmethod
-    def build(cls, tris, nppl=5):
+    def build(cls, tris, nppl=5, extra_levels=None):
+        """rtBuildBvh; extra_levels: rtBuildBvhLevels (None = the builder's default)."""
         tris = np.ascontiguousarray(tris, dtype=triangle_dtype)
-        return cls(load_host().rtBuildBvh(tris.ctypes.data, len(tris), nppl))
+        if extra_levels is None:
+            return cls(load_host().rtBuildBvh(tris.ctypes.data, len(tris), nppl))
+        return cls(load_host().rtBuildBvhLevels(tris.ctypes.data, len(tris), nppl, extra_levels))
 
     @classmethod
     def load(cls, path):

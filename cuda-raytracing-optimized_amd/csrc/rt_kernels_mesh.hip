@@ -54,6 +54,7 @@ __device__ __forceinline__ Tri load_tri(const rt_triangle* tris, uint32_t id) {
 }
 
 struct TravStats { uint32_t nodes, tests; };
+typedef float f4u __attribute__((ext_vector_type(4)));
 
 // hitBvh (DUAL_NODES), kernels.cu:154-224
 __device__ __forceinline__ float hit_bvh(const RtMeshParams& P, const Ray& r, float t_min, float t_max, bool is_shadow,
@@ -282,6 +283,7 @@ struct Job {
     uint32_t triId;
     float hu, hv;
     bool shadow;
+    uint32_t ax, ay, az;    // byte offsets of the ray's (near_L, near_R, far_L, far_R) on each axis inside a bvh_axis record
 };
 
 __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org, f3 dir, float t_min, float t_max, bool shadow) {
@@ -291,6 +293,9 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
     J.closest = t_max;
     J.bitStack = 1;
     J.triId = 0; J.hu = 0.0f; J.hv = 0.0f;
+    J.ax = J.r.inv.x < 0.0f ? 16u : 0u;                  // `if (invD < 0.0f) swap(t0, t1)`, intersections.h:30, as a choice of address
+    J.ay = J.r.inv.y < 0.0f ? 48u : 32u;
+    J.az = J.r.inv.z < 0.0f ? 80u : 64u;
     // hitMesh, kernels.cu:296-323: scene bounds first; a miss reports FLT_MAX
     if (hit_bbox(ld3(P.bounds.min), ld3(P.bounds.max), J.r, t_max)) {
         J.idx = 1;
@@ -573,14 +578,24 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     const bool at_node = J.idx != 0 && (uint32_t)J.idx < P.first_leaf;
                     if (at_node) {
                         const int idx2 = J.idx << 1;
-                        const float4* n = P.bvh4 + (size_t)J.idx * 3;
-                        const float4 na = n[0], nb = n[1], nc = n[2];
+                        // child pair of node idx from its axis-grouped record (rt_params.h): per axis (near_L, near_R, far_L, far_R)
+                        const char* rec = reinterpret_cast<const char*>(P.bvh_axis);
+                        const uint32_t rb = __umul24((uint32_t)J.idx, 96u);
+                        const f4u px = *reinterpret_cast<const f4u*>(rec + (rb + J.ax));
+                        const f4u py = *reinterpret_cast<const f4u*>(rec + (rb + J.ay));
+                        const f4u pz = *reinterpret_cast<const f4u*>(rec + (rb + J.az));
                         if (COUNT) st.nodes++;
                         // leftHit / rightHit of kernels.cu:175-181 are (hit ? entry : FLT_MAX); only compared, so kept as (hit, entry):
-                        // `x < closest` = hit && entry < closest (closest <= FLT_MAX), `rightHit < leftHit` = as below when one side is taken
-                        float le, re;
-                        const bool hl = hit_bbox_entry(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest, le);
-                        const bool hr = hit_bbox_entry(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest, re);
+                        // `x < closest` = hit && entry < closest (closest <= FLT_MAX), `rightHit < leftHit` = as below when one side is taken.
+                        // hit_bbox_dist (intersections.h:25-41) per box: t_min from 0.001f, t_max from closest, v_max / v_min updates (rt_device.h slab)
+                        float le = 0.001f, re = 0.001f, lx = J.closest, rx = J.closest;
+                        le = fmaxf((px.x - J.r.o.x) * J.r.inv.x, le); lx = fminf((px.z - J.r.o.x) * J.r.inv.x, lx);
+                        re = fmaxf((px.y - J.r.o.x) * J.r.inv.x, re); rx = fminf((px.w - J.r.o.x) * J.r.inv.x, rx);
+                        le = fmaxf((py.x - J.r.o.y) * J.r.inv.y, le); lx = fminf((py.z - J.r.o.y) * J.r.inv.y, lx);
+                        re = fmaxf((py.y - J.r.o.y) * J.r.inv.y, re); rx = fminf((py.w - J.r.o.y) * J.r.inv.y, rx);
+                        le = fmaxf((pz.x - J.r.o.z) * J.r.inv.z, le); lx = fminf((pz.z - J.r.o.z) * J.r.inv.z, lx);
+                        re = fmaxf((pz.y - J.r.o.z) * J.r.inv.z, re); rx = fminf((pz.w - J.r.o.z) * J.r.inv.z, rx);
+                        const bool hl = !(lx < le), hr = !(rx < re);
                         const bool traverseLeft = hl && le < J.closest;
                         const bool traverseRight = hr && re < J.closest;
                         const bool swap = traverseRight && (!traverseLeft || re < le);
@@ -643,16 +658,16 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                                 const float4 ta = pt[0], tb = pt[1];
                                 const float tcx = pt[2].x;
                                 reached = !isinf(ta.x);                  // kernels.cu:202 sentinel; sentinels are trailing (checked on the host)
-                                if (reached) {
-                                    Ray pr;
-                                    pr.o = F3(ox, oy, oz); pr.d = F3(dx, dy, dz); pr.inv = F3(0, 0, 0);
-                                    const float hitT = triangle_hit(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tcx), pr, eps, o_closest, u, v);
-                                    hit = hitT < o_closest;
-                                    if (hit) {
-                                        key = o_shadow ? (unsigned long long)pair_k
-                                                       : (((unsigned long long)__float_as_uint(hitT) << 32) | (unsigned long long)pair_k);
-                                        atomicMin(&w_best[owner], key);
-                                    }
+                                // the test runs on a sentinel too (its NaNs fail every compare -> FLT_MAX): behind `if (reached)` the compiler
+                                // issued the loads of tb / tcx only after ta had arrived - two memory round trips per pair round
+                                Ray pr;
+                                pr.o = F3(ox, oy, oz); pr.d = F3(dx, dy, dz); pr.inv = F3(0, 0, 0);
+                                const float hitT = triangle_hit(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tcx), pr, eps, o_closest, u, v);
+                                hit = reached && hitT < o_closest;
+                                if (hit) {
+                                    key = o_shadow ? (unsigned long long)pair_k
+                                                   : (((unsigned long long)__float_as_uint(hitT) << 32) | (unsigned long long)pair_k);
+                                    atomicMin(&w_best[owner], key);
                                 }
                             }
                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -80,6 +80,10 @@ struct RtMeshParams {
     int32_t nx, ny, ns, max_depth;
     const rt_triangle* tris;
     const float4* bvh4;         // heap-indexed nodes viewed as float4 texels: child pair of node i at texels 3i..3i+2
+    const float* bvh_axis;      // the same child pairs, one 96-byte record per internal node i, grouped by AXIS: for a in x,y,z the eight floats
+                                // {min_L, min_R, max_L, max_R | max_L, max_R, min_L, min_R} (L = node 2i, R = node 2i+1): a ray reads one float4 per
+                                // axis, the first (1/dir >= 0) or the second (1/dir < 0), and gets (near_L, near_R, far_L, far_R) - the swap of
+                                // intersections.h:30 done by the address (default kernel only)
     uint32_t first_leaf;
     uint32_t nppl;
     int32_t leaf_sentinels_trailing;   // host-checked: no real triangle behind a sentinel in any leaf (pair rounds allowed)

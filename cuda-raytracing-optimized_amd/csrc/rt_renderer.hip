@@ -59,6 +59,7 @@ struct DeviceState {
     // mesh scene
     rt_triangle* d_tris = nullptr;
     float4* d_bvh = nullptr;
+    float* d_bvh_axis = nullptr;
     rt_material* d_materials = nullptr;
     std::vector<float*> d_tex;
     float** d_tex_data = nullptr;
@@ -98,6 +99,7 @@ struct RenderContext {
     int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0, n_big = 0;
     std::vector<rt_triangle> h_tris;
     std::vector<float4> h_bvh;          // numBvhNodes * 24 B viewed as float4 (padded)
+    std::vector<float> h_bvh_axis;      // RtMeshParams::bvh_axis
     int num_bvh_nodes = 0;
     int nppl = 0;
     int leaf_sentinels_trailing = 1;
@@ -136,7 +138,7 @@ void free_device(DeviceState& d) {
     if (d.stream) HIP_CHECK(hipStreamSynchronize(d.stream));
     auto fr = [](void* p) { if (p) HIP_CHECK(hipFree(p)); };
     fr(d.d_spheres); fr(d.d_rad); fr(d.d_mat_color); fr(d.d_mat_type); fr(d.d_groups); fr(d.d_orig); fr(d.d_slot_of);
-    fr(d.d_tris); fr(d.d_bvh); fr(d.d_materials);
+    fr(d.d_tris); fr(d.d_bvh); fr(d.d_bvh_axis); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
     fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays);
@@ -193,6 +195,7 @@ void setup_devices() {
         } else {
             d.d_tris = upload(c.h_tris);
             d.d_bvh = upload(c.h_bvh);
+            d.d_bvh_axis = upload(c.h_bvh_axis);
             d.d_materials = upload(c.h_materials);
             const int nt = (int)c.h_tex.size();
             if (nt > 0) {
@@ -432,6 +435,20 @@ void initRenderer(const rt_kernel_scene sc, const rt_camera cam, rt_vec3** fb, i
     const size_t nfloats = (size_t)c.num_bvh_nodes * 6;
     c.h_bvh.assign((nfloats + 3) / 4 + 1, make_float4(0, 0, 0, 0));
     memcpy(c.h_bvh.data(), sc.m->bvh, nfloats * sizeof(float));
+    {   // axis-grouped child-pair records (rt_params.h, bvh_axis): 24 floats per internal node
+        const size_t nrec = (size_t)c.num_bvh_nodes / 2;
+        c.h_bvh_axis.assign(nrec * 24, 0.0f);
+        const float* nodes = reinterpret_cast<const float*>(sc.m->bvh);
+        for (size_t i = 0; i < nrec; i++) {
+            const float* L = nodes + (2 * i) * 6;
+            const float* R = nodes + (2 * i + 1) * 6;
+            for (int a = 0; a < 3; a++) {
+                float* o = c.h_bvh_axis.data() + i * 24 + a * 8;
+                o[0] = L[a]; o[1] = R[a]; o[2] = L[3 + a]; o[3] = R[3 + a];
+                o[4] = L[3 + a]; o[5] = R[3 + a]; o[6] = L[a]; o[7] = R[a];
+            }
+        }
+    }
     c.nppl = sc.numPrimitivesPerLeaf;                                                          // kernels.cu:648
     // The leaf loop of kernels.cu:196-214 stops at the first sentinel (inf) triangle of a leaf.  The pair rounds of the mesh
     // kernel test a leaf's triangles in parallel and rely on sentinels being TRAILING (true for every builder that pads
@@ -568,7 +585,7 @@ void runRenderer(int ns, int tx, int ty) {
             RtMeshParams p;
             memset(&p, 0, sizeof p);
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
-            p.tris = d.d_tris; p.bvh4 = d.d_bvh;
+            p.tris = d.d_tris; p.bvh4 = d.d_bvh; p.bvh_axis = d.d_bvh_axis;
             p.first_leaf = (uint32_t)c.num_bvh_nodes / 2; p.nppl = (uint32_t)c.nppl; p.bounds = c.bounds;
             p.leaf_sentinels_trailing = c.leaf_sentinels_trailing;
             p.materials = d.d_materials;

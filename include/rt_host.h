@@ -47,6 +47,9 @@ typedef struct rt_host_mesh rt_host_mesh;    /* opaque; owns tris + bvh */
  * node 0 unused, leaves = power of two, nppl triangles per leaf padded with sentinel triangles
  * whose v[0].x is +inf (kernels.cu:202).  Returns NULL on bad arguments. */
 rt_host_mesh* rtBuildBvh(const rt_triangle* tris, int num_tris, int nppl);
+/* The same with `extra_levels` tree levels beyond the smallest complete tree that holds the triangles (rtBuildBvh: 1): more leaf
+ * slots for the SAH cuts to use - fewer node visits and triangle tests per ray, twice the (small) arrays per level. */
+rt_host_mesh* rtBuildBvhLevels(const rt_triangle* tris, int num_tris, int nppl, int extra_levels);
 
 /* loadBVH, /root/reference/staircase_scene.h:75-101: file "BVH_00.04\0", int numTris,
  * triangle[numTris], int numBvhNodes, bvh_node[numBvhNodes], vec3 min, vec3 max, int nppl. */
