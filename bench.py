@@ -55,7 +55,7 @@ WORKLOADS = {
     "C3": dict(kind="spheres", nx=1200, ny=800, spp=1000, depth=50,
                name="random-spheres (488 spheres) 1200x800 1000spp maxDepth 50"),
     "C4": dict(kind="mesh", nx=1920, ny=1080, spp=256, depth=64, detail=4,
-               name="procedural staircase mesh (36380 triangles, 16384-node BVH, 5 per leaf) 1920x1080 256spp maxDepth 64, "
+               name="procedural staircase mesh (36380 triangles, 32768-node BVH of rtBuildBvh, 5 per leaf) 1920x1080 256spp maxDepth 64, "
                     "NEE + Russian roulette, constant sky (kernels.cu HEAD defaults) through initRenderer"),
     "C5": dict(kind="spheres", nx=3840, ny=2160, spp=4096, depth=50,
                name="random-spheres (488 spheres, LCG seed 0) 3840x2160 4096spp maxDepth 50, gradient sky"),
@@ -234,8 +234,12 @@ def mesh_roofline(job, world, traffic=None):
          "kernel": "k_render_mesh_queue", "kernel_ms_avg": job["kernel_ms"],
          "per_sample": {k: c[k] / job["samples"] for k in ("rays", "shadow_rays", "node_visits", "prim_tests")},
          "note": "algorithmic gather bytes = 48 x node visits + 64 x triangle tests + 64 x rays (device counters, equal to the oracle's) / kernel time; "
-                 "peak = chip-wide L2-served row-gather rate (MI355X_MICROARCH.md, 'Indexed rows'); the 3 MB working set never leaves L2"}
+                 "peak = chip-wide L2-served row-gather rate (MI355X_MICROARCH.md, 'Indexed rows'). The rays touch 1.5 MB of node records and "
+                 "5.2 MB of triangle slots: more than one XCD's 4 MB L2, the rest is served by the Infinity Cache - `traffic` (FETCH_SIZE + WRITE_SIZE, "
+                 "the bytes that leave L2) is compared with THESE gather bytes, not with the framebuffer"}
     r.update(traffic or {"traffic": None})
+    if r.get("traffic"):
+        r["traffic_over_algorithmic"] = r["traffic"] / by
     return r
 
 

@@ -59,8 +59,11 @@ for W, per_frame in (("C2", 2), ("C4", 1)):
         by = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
         w = bench.WORKLOADS[W]
         alg = w["nx"] * w["ny"] * 12
-        lines.append("HBM-side bytes per frame = (2 x FETCH_SIZE + WRITE_SIZE) KB = %.1f MB read + %.1f MB written = %.1f MB; algorithmic framebuffer bytes %.1f MB -> x%.1f" %
+        lines.append("bytes that leave L2 per frame = (2 x FETCH_SIZE + WRITE_SIZE) KB = %.1f MB read + %.1f MB written = %.1f MB; algorithmic framebuffer bytes %.1f MB -> x%.1f" %
                      (2 * g("FETCH_SIZE") / 1024, g("WRITE_SIZE") / 1024, by / 1e6, alg / 1e6, by / alg))
+        if W == "C4":
+            lines.append("(C4: the reads are node records and triangle slots - 6.7 MB touched, one XCD's L2 holds 4 MB, the Infinity Cache the rest; the kernel's "
+                         "algorithmic GATHER bytes, which its roofline counts, are ~4 TB per frame: bench.py other_configs.C4.roofline)")
         out[W] = {"bytes_per_frame": by, "fetch_kb_x2": 2 * g("FETCH_SIZE"), "write_kb": g("WRITE_SIZE"), "frame_ms": (sum(frames) / len(frames)) if frames else None,
                   "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes around tools/one_frame.py, FETCH x2 (gfx950), last full frame"}
     open(os.path.join(ROOT, "gpurun_out", f"{tag}_{W}_summary.txt"), "w").write("\n".join(lines) + "\n")
