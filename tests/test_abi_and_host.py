@@ -103,11 +103,17 @@ def test_bvh_builder_layout_contract(rt):
     +inf sentinels end a leaf, parents bound children, every input triangle appears exactly once."""
     tris, mats = rt.scene_staircase_procedural(1)
     assert len(mats) == 20 and len(tris) > 1000
-    for nppl in (1, 5, 8):
-        hm = rt.HostMesh.build(tris, nppl)
+    minimal = {}
+    for nppl, extra in ((5, 0), (1, None), (5, None), (8, None), (5, 2)):
+        hm = rt.HostMesh.build(tris, nppl, extra)
         v = hm.view
         leaves = v.numBvhNodes // 2
         assert v.numBvhNodes == 2 * leaves and leaves & (leaves - 1) == 0 and leaves >= 2
+        if extra == 0:
+            minimal[nppl] = leaves
+            assert (leaves // 2) * nppl < len(tris) or leaves == 2          # the smallest complete tree that holds them
+        if nppl == 5 and extra in (None, 2):                                # rtBuildBvh = one level more, rtBuildBvhLevels as asked
+            assert leaves == minimal[5] << (1 if extra is None else extra)
         assert v.numTris == leaves * nppl and leaves * nppl >= len(tris)
         out = hm.tris
         real = ~np.isinf(out["v"][:, 0, 0])
@@ -131,6 +137,19 @@ def test_bvh_builder_layout_contract(rt):
                 assert np.all(lo[L] <= t["v"].min(axis=(0, 1))) and np.all(hi[L] >= t["v"].max(axis=(0, 1)))
         assert np.array_equal(np.array(v.bounds.min.e[:], np.float32), lo[1]) and np.array_equal(np.array(v.bounds.max.e[:], np.float32), hi[1])
         hm.close()
+
+
+def test_an_extra_tree_level_saves_traversal_work(rt, O):
+    """rtBuildBvhLevels: more leaf slots for the SAH cuts -> fewer node visits and triangle tests for the same rays (the oracle's counters)."""
+    tris, mats = rt.scene_staircase_procedural(2)
+    cam = rt.staircase_camera(64, 36)
+    work = []
+    for extra in (0, 1):
+        hm = rt.HostMesh.build(tris, 5, extra)
+        _, c = O.render(O.mesh_scene(hm, mats), cam, O.default_options(False), 64, 36, 1, 64, counters=True)
+        work.append((c.node_visits, c.prim_tests))
+        hm.close()
+    assert work[1][0] < work[0][0] and work[1][1] < work[0][1], work
 
 
 def test_bvh_file_round_trip(rt, tmp_path):
