@@ -1360,7 +1360,10 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     if (blocks < 1) blocks = 1;
     // scattered order: stride ~ 0.618 * total, coprime with total
     uint32_t stride = 1;
-    const int order_mode = (variant >> 24) & 3;
+    int order_mode = (variant >> 24) & 3;
+    // A scene copy above 80 KB leaves ONE workgroup per CU (two waves per SIMD): there the coherent waves of the tile-major single dispatch beat the
+    // cost-ordered two dispatches (tools/sweep_scene_sizes.py, 1200x800x50: 900 spheres 2518 against 2483, 1100: 2269 / 2113, 1500: 1948 / 1591).
+    if (order_mode == 0 && !p.global_scene && lds > 80 * 1024) order_mode = 1;
     if (order_mode != 1 && total_px > 64) {
         auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
         unsigned long long cand = (unsigned long long)((double)total_px * 0.6180339887) | 1ull;
