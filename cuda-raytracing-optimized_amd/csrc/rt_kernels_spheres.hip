@@ -96,7 +96,7 @@ __device__ __forceinline__ int sidx(int slot) { return slot + (slot >> kSphereGr
 struct SceneLds {
     const float4* sph;      // (cx, cy, cz, r*r) of slot k at index sidx(k) = k + k/16: 17 float4 per group of 16, so that
                             // lanes reading DIFFERENT groups in one ds_read_b128 fall on different banks (pair scan)
-    const float4* grp;      // 2 x n_groups: AABB (lo, hi) of each group of 16 slots
+    const float4* grp;      // 3 x n_groups: per group and AXIS (lo, hi, lo, -) of the AABB of its 16 slots (see box_reach)
     const float4* mat;      // n_padded x (r, g, b, param)
     const int*    typ;      // n_padded
     const int*    orig;     // n_padded: the caller's sphere index of each slot (INT_MAX for pad slots)
@@ -113,7 +113,7 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     }
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
-    float4* s_mat = s_grp + 2 * P.n_groups;
+    float4* s_mat = s_grp + 3 * P.n_groups;
     int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
     int*    s_org = s_typ + P.n_padded;
     float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
@@ -125,7 +125,7 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
     }
-    for (int k = threadIdx.x; k < 2 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
+    for (int k = threadIdx.x; k < 3 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
     for (int k = threadIdx.x; k < P.n; k += kThreads) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
     *after = s_fb;                                                   // WITH_FB (tile kernel): kThreads x 3 floats of framebuffer staging
@@ -273,7 +273,9 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
 //  * a NaN (0 * inf, inf - inf on a slab plane / axis-parallel ray) is dropped by min / max, i.e. ignores that axis: keeps the node.
 // Not being part of the reference's arithmetic, the test may use what is fastest: v_rcp_f32 and fused multiply-adds
 // (lo * inv - (org + m) * inv: six v_fma_f32 per box instead of twelve sub / mul).
-struct BoxRay { f3 inv, clo, chi; float cb; };
+// The two planes of an axis are not ordered by min / max after the fact: the box stores (lo, hi, lo) per axis and the ray reads two consecutive
+// floats at offset 0 (direction >= 0: near = lo, far = hi) or 1 (near = hi, far = lo) - six VALU instructions fewer per box.
+struct BoxRay { f3 inv, cn, cf; float cb; uint32_t sx, sy, sz; };   // cn / cf: (org +- m) * inv of the near / far plane; s*: 0 or 1
 
 __device__ __forceinline__ BoxRay make_box_ray(const RtSphereParams& P, f3 org, f3 dn, float closest) {
     BoxRay r;
@@ -281,19 +283,23 @@ __device__ __forceinline__ BoxRay make_box_ray(const RtSphereParams& P, f3 org, 
     const f3 dc = org - F3(P.cull_cx, P.cull_cy, P.cull_cz);
     const float D = __builtin_amdgcn_sqrtf(dot(dc, dc)) * 1.000001f + P.cull_radius;
     const float m = fminf(P.cull_k1 * D * D, P.cull_k2 * D) + P.cull_k3 * (fmaxf(fmaxf(fabsf(org.x), fabsf(org.y)), fabsf(org.z)) + P.cull_coord_max);
-    r.clo = F3((org.x + m) * r.inv.x, (org.y + m) * r.inv.y, (org.z + m) * r.inv.z);
-    r.chi = F3((org.x - m) * r.inv.x, (org.y - m) * r.inv.y, (org.z - m) * r.inv.z);
+    // plane lo - m: t = lo * inv - (org + m) * inv; plane hi + m: t = hi * inv - (org - m) * inv
+    const f3 clo = F3((org.x + m) * r.inv.x, (org.y + m) * r.inv.y, (org.z + m) * r.inv.z);
+    const f3 chi = F3((org.x - m) * r.inv.x, (org.y - m) * r.inv.y, (org.z - m) * r.inv.z);
+    r.sx = __float_as_uint(r.inv.x) >> 31; r.sy = __float_as_uint(r.inv.y) >> 31; r.sz = __float_as_uint(r.inv.z) >> 31;
+    r.cn = F3(r.sx ? chi.x : clo.x, r.sy ? chi.y : clo.y, r.sz ? chi.z : clo.z);
+    r.cf = F3(r.sx ? clo.x : chi.x, r.sy ? clo.y : chi.y, r.sz ? clo.z : chi.z);
     r.cb = (closest + 1.0e-4f) * 1.00002f;
     return r;
 }
 
-// true = the ray may reach the box [lo - m, hi + m] at a distance <= its current closest hit
-__device__ __forceinline__ bool box_reach(float4 lo, float4 hi, const BoxRay& r) {
-    const float x0 = __builtin_fmaf(lo.x, r.inv.x, -r.clo.x), x1 = __builtin_fmaf(hi.x, r.inv.x, -r.chi.x);
-    const float y0 = __builtin_fmaf(lo.y, r.inv.y, -r.clo.y), y1 = __builtin_fmaf(hi.y, r.inv.y, -r.chi.y);
-    const float z0 = __builtin_fmaf(lo.z, r.inv.z, -r.clo.z), z1 = __builtin_fmaf(hi.z, r.inv.z, -r.chi.z);
-    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+// true = the ray may reach the box [lo - m, hi + m] at a distance <= its current closest hit.  `g3` = the group's three float4.
+__device__ __forceinline__ bool box_reach(const float4* g3, const BoxRay& r) {
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    const float* f = reinterpret_cast<const float*>(g3);
+    const f2u px = *reinterpret_cast<const f2u*>(f + r.sx), py = *reinterpret_cast<const f2u*>(f + 4 + r.sy), pz = *reinterpret_cast<const f2u*>(f + 8 + r.sz);
+    const float t_in = fmaxf(fmaxf(__builtin_fmaf(px.x, r.inv.x, -r.cn.x), __builtin_fmaf(py.x, r.inv.y, -r.cn.y)), __builtin_fmaf(pz.x, r.inv.z, -r.cn.z));
+    const float t_out = fminf(fminf(__builtin_fmaf(px.y, r.inv.x, -r.cf.x), __builtin_fmaf(py.y, r.inv.y, -r.cf.y)), __builtin_fmaf(pz.y, r.inv.z, -r.cf.z));
     // skip iff (t_in > t_out) || (t_out < 0) || (t_in > cb), cb >= 0
     return !(fmaxf(t_in, 0.0f) > fminf(t_out, r.cb));
 }
@@ -303,8 +309,7 @@ __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int n
     uint32_t need = 0;
 #pragma unroll 4
     for (int g = 0; g < ng; g++) {
-        const float4 lo = S.grp[2 * (g0 + g)], hi = S.grp[2 * (g0 + g) + 1];
-        need |= (box_reach(lo, hi, br) ? 1u : 0u) << g;
+        need |= (box_reach(S.grp + 3 * (g0 + g), br) ? 1u : 0u) << g;
     }
     return need;
 }
@@ -576,8 +581,8 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
         w_best[my_r] = ~0ull;
         const BoxRay b = make_box_ray(P, org, dn, 0.0f);             // once per ray (margin, reciprocals), not once per (ray, group) item
         w_box[3 * my_r] = make_float4(b.inv.x, b.inv.y, b.inv.z, 0.0f);
-        w_box[3 * my_r + 1] = make_float4(b.clo.x, b.clo.y, b.clo.z, 0.0f);
-        w_box[3 * my_r + 2] = make_float4(b.chi.x, b.chi.y, b.chi.z, 0.0f);
+        w_box[3 * my_r + 1] = make_float4(b.cn.x, b.cn.y, b.cn.z, 0.0f);
+        w_box[3 * my_r + 2] = make_float4(b.cf.x, b.cf.y, b.cf.z, 0.0f);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -609,9 +614,10 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
                 const float closest = __uint_as_float((uint32_t)(w_best[r] >> 32));   // FLT_MAX-or-larger bit pattern if none: keeps everything
                 const float4 b0 = w_box[3 * r], b1 = w_box[3 * r + 1], b2 = w_box[3 * r + 2];
                 BoxRay br;
-                br.inv = F3(b0.x, b0.y, b0.z); br.clo = F3(b1.x, b1.y, b1.z); br.chi = F3(b2.x, b2.y, b2.z);
+                br.inv = F3(b0.x, b0.y, b0.z); br.cn = F3(b1.x, b1.y, b1.z); br.cf = F3(b2.x, b2.y, b2.z);
+                br.sx = __float_as_uint(b0.x) >> 31; br.sy = __float_as_uint(b0.y) >> 31; br.sz = __float_as_uint(b0.z) >> 31;
                 br.cb = (fminf(closest, FLT_MAX) + 1.0e-4f) * 1.00002f;
-                reach = box_reach(S.grp[2 * g], S.grp[2 * g + 1], br);
+                reach = box_reach(S.grp + 3 * g, br);
             }
         }
         const unsigned long long rm = __ballot(reach);
@@ -1277,7 +1283,7 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 static size_t lds_bytes(int n_padded, int n, bool with_fb) {
     // spheres + group bounds + material colour + type / original index / radius per slot + slot_of,
     // + fb staging (tile kernel only) + the per-wave scratch
-    return (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 32 +
+    return (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 +
            (size_t)n_padded * 16 + (size_t)n_padded * 12 +
            (size_t)((n + 3) & ~3) * 4 + (with_fb ? (size_t)kThreads * 3 * 4 : 0) + (size_t)kWavesPerWg * kWaveScratch;
 }

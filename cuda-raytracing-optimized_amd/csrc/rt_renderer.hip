@@ -92,7 +92,7 @@ struct RenderContext {
     int global_scene = 0;
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
-    std::vector<float4> h_groups;       // two float4 per group of kSphereGroup slots: inflated AABB lo / hi
+    std::vector<float4> h_groups;       // three float4 per group of kSphereGroup slots: per axis (lo, hi, lo, -) of the tight AABB
     float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0;
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
@@ -327,9 +327,9 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     c.h_mat_type.assign(c.n_padded, RT_DIFFUSE);
     c.h_orig.assign(c.n_padded, INT_MAX);
     c.h_slot_of.assign(n, 0);
-    // bounds: 2 float4 per group = AABB lo / hi.  Empty group: lo > hi on every axis (never reachable).
-    c.h_groups.assign((size_t)c.n_groups * 2, make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f));
-    for (int g = 0; g < c.n_groups; g++) c.h_groups[2 * g + 1] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f);
+    // bounds: 3 float4 per group, one per AXIS: (lo, hi, lo, -) - a ray reads two consecutive floats, at 0 or at 1 by the sign of its direction,
+    // and has (near plane, far plane).  Empty group: lo > hi on every axis (never reachable).
+    c.h_groups.assign((size_t)c.n_groups * 3, make_float4(3.0e38f, -3.0e38f, 3.0e38f, 0.0f));
     for (int s = 0; s < c.n_padded; s++) {
         const int k = slots[s];
         if (k < 0) continue;
@@ -367,8 +367,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
             fhi[a] = std::nextafter((float)bhi[a], INFINITY);
             coord_max = std::max(coord_max, std::max(fabsf(flo[a]), fabsf(fhi[a])));
         }
-        c.h_groups[2 * g] = make_float4(flo[0], flo[1], flo[2], 0.0f);
-        c.h_groups[2 * g + 1] = make_float4(fhi[0], fhi[1], fhi[2], 0.0f);
+        for (int a = 0; a < 3; a++) c.h_groups[3 * g + a] = make_float4(flo[a], fhi[a], flo[a], 0.0f);
     }
     // per-ray margin constants
     double cc[3] = { 0, 0, 0 }, rad = 0.0;
