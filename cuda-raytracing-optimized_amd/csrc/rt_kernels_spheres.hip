@@ -293,25 +293,27 @@ __device__ __forceinline__ BoxRay make_box_ray(const RtSphereParams& P, f3 org, 
     return r;
 }
 
-// true = the ray may reach the box [lo - m, hi + m] at a distance <= its current closest hit.  `g3` = the group's three float4.
-__device__ __forceinline__ bool box_reach(const float4* g3, const BoxRay& r) {
+// >= 0 (sign bit clear) = the ray may reach the box [lo - m, hi + m] at a distance <= its current closest hit.  `g3` = the group's three
+// float4.  Both terms are NaN-free (v_max3 / v_min3 drop NaN operands and each has a finite one) and never both +inf, so the difference is no NaN.
+__device__ __forceinline__ float box_gap(const float4* g3, const BoxRay& r) {
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     const float* f = reinterpret_cast<const float*>(g3);
     const f2u px = *reinterpret_cast<const f2u*>(f + r.sx), py = *reinterpret_cast<const f2u*>(f + 4 + r.sy), pz = *reinterpret_cast<const f2u*>(f + 8 + r.sz);
     const float t_in = fmaxf(fmaxf(__builtin_fmaf(px.x, r.inv.x, -r.cn.x), __builtin_fmaf(py.x, r.inv.y, -r.cn.y)), __builtin_fmaf(pz.x, r.inv.z, -r.cn.z));
     const float t_out = fminf(fminf(__builtin_fmaf(px.y, r.inv.x, -r.cf.x), __builtin_fmaf(py.y, r.inv.y, -r.cf.y)), __builtin_fmaf(pz.y, r.inv.z, -r.cf.z));
     // skip iff (t_in > t_out) || (t_out < 0) || (t_in > cb), cb >= 0
-    return !(fmaxf(t_in, 0.0f) > fminf(t_out, r.cb));
+    return fminf(t_out, r.cb) - fmaxf(t_in, 0.0f);
 }
+__device__ __forceinline__ bool box_reach(const float4* g3, const BoxRay& r) { return !(box_gap(g3, r) < 0.0f); }
 
 __device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, const BoxRay& br, bool cull) {
     if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
-    uint32_t need = 0;
+    // the skip flags are the SIGN BITS of the gaps, shifted in one v_alignbit per box (compare + select + shift + or otherwise);
+    // box g of the pass ends up at bit ng - 1 - g: one bit reversal per pass puts it back at bit g
+    uint32_t skip = 0;
 #pragma unroll 4
-    for (int g = 0; g < ng; g++) {
-        need |= (box_reach(S.grp + 3 * (g0 + g), br) ? 1u : 0u) << g;
-    }
-    return need;
+    for (int g = 0; g < ng; g++) skip = __builtin_amdgcn_alignbit(skip, __float_as_uint(box_gap(S.grp + 3 * (g0 + g), br)), 31);
+    return __brev(~skip << (32 - ng));                               // 1 <= ng <= kPassGroups (16)
 }
 
 // Inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15
