@@ -457,7 +457,15 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 const int sbase = sidx(slot0);
                 const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
-                const float A = ro.w;
+                // A pair round only has to FIND the spheres whose discriminant (intersections.h:90-93: b*b - a*c, every product and sum rounded)
+                // is positive; their hits are then computed literally by resolve().  So the round evaluates -(b*b - a*c) with fused
+                // multiply-adds (12 instead of 18 instructions per sphere) and flags what is below a slack that covers the difference between
+                // the two evaluations: with S = |oc|^2 both differ from the real value by at most 13 eps (S + r^2) (three-term sums of
+                // products, |b| <= sqrt(S a), a = 1), i.e. from each other by 26 eps (S + r^2), eps = 2^-24.  Flagged: nd_fma < kPairSlack
+                // (S + r^2) with kPairSlack = 2^-18 = 64 eps; S + r^2 = c + 2 r^2 <= c + 2 r_max^2, folded into the two last operations:
+                // nd_fma - slack = (a - kPairSlack) c - (b b + pair_k0).  A flagged sphere that the reference's arithmetic rejects costs one
+                // exact test and changes nothing (resolve() returns FLT_MAX for it).
+                const float Ak = ro.w - 3.814697265625e-6f;
                 groups_done += (uint32_t)(spl >> 2);                 // in units of 4 sphere tests
                 uint32_t mask = 0;
                 for (int k4 = 0; k4 < spl; k4 += 4) {
@@ -467,10 +475,10 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                         const float ocx = O.x - sph.x;
                         const float ocy = O.y - sph.y;
                         const float ocz = O.z - sph.z;
-                        const float b = ocx * D.x + ocy * D.y + ocz * D.z;
-                        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sph.w;
-                        const float nd = A * c - b * b;              // == -(b*b - a*c) bit for bit
-                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(nd), 31);
+                        const float b = __builtin_fmaf(ocz, D.z, __builtin_fmaf(ocy, D.y, ocx * D.x));
+                        const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -sph.w)));
+                        const float v = __builtin_fmaf(Ak, c, -__builtin_fmaf(b, b, P.pair_k0));
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(v), 31);
                     }
                 }
                 mask <<= (32 - spl);                                 // slot0 at bit 31

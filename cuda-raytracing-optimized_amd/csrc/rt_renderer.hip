@@ -93,7 +93,7 @@ struct RenderContext {
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
     std::vector<float4> h_groups;       // three float4 per group of kSphereGroup slots: per axis (lo, hi, lo, -) of the tight AABB
-    float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0;
+    float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0, pair_k0 = 0;
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
     int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0, n_big = 0;
@@ -386,6 +386,9 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     c.cull_k2 = (float)std::sqrt(K_eps);
     c.cull_k3 = 16.0f * 5.9604645e-8f;
     c.cull_coord_max = coord_max;
+    double r_max_small = 0.0;
+    for (int k : small) r_max_small = std::max(r_max_small, (double)radii[k]);
+    c.pair_k0 = (float)(2.0 * 3.814697265625e-6 * r_max_small * r_max_small * 1.0001);     // 2 x kPairSlack (2^-18) x r_max^2, rounded up
     (void)extent;
 }
 
@@ -545,7 +548,7 @@ void runRenderer(int ns, int tx, int ty) {
             p.spheres = d.d_spheres; p.rad = d.d_rad; p.global_scene = c.global_scene; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
-            p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max;
+            p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max; p.pair_k0 = c.pair_k0;
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
