@@ -558,11 +558,13 @@ constexpr int kSparseRays = 4;
 __device__ __forceinline__ void sparse_test_slot(const RtSphereParams& P, const SceneLds& S, int slot, f3 O, f3 D, float A,
                                                  unsigned long long* best) {
     const float4 sph = S.sph[sidx(slot)];
+    // positive discriminants are FOUND with fused multiply-adds and the slack of the pair rounds (scan_pairs), here with the sphere's own
+    // radius (big spheres come this way too): flagged iff nd_fma < 2^-18 (S + r^2) = 2^-18 (c + 2 r^2); the hit itself is literal
     const f3 oc = O - F3(sph.x, sph.y, sph.z);
-    const float b = oc.x * D.x + oc.y * D.y + oc.z * D.z;
-    const float c = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - sph.w;
-    const float nd = A * c - b * b;
-    if (nd < 0.0f) {
+    const float b = __builtin_fmaf(oc.z, D.z, __builtin_fmaf(oc.y, D.y, oc.x * D.x));
+    const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -sph.w)));
+    const float v = __builtin_fmaf(A - 3.814697265625e-6f, c, -__builtin_fmaf(b, b, 7.62939453125e-6f * sph.w));
+    if (v < 0.0f) {
         const float t = sphere_hit_exact(sph, O, D, A, P.t_min, FLT_MAX);
         const int o = S.orig[slot];
         if (o != 0x7fffffff && t < FLT_MAX)
