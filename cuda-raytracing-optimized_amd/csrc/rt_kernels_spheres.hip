@@ -30,7 +30,8 @@
 //   * framebuffer: the persistent kernels (default) store a finished pixel with ONE 12-byte store from the lane that owns it
 //     (pixels finish one by one, in cost order); only the tile kernel (variant 1) transposes its 8x8 tile through LDS so that a
 //     wave writes row-contiguous dwords;
-//   * scenes that do not fit the LDS (> ~2100 spheres) are read from global memory by the same kernel (template flag GLOBAL).
+//   * the scene copy of a workgroup comes in three forms (stage_scene, template parameter SCENE): everything in the LDS; the test data in the LDS and the
+//     hit data in global memory (two workgroups per CU up to ~1500 spheres, LDS-resident up to ~5000); everything read from global memory beyond that.
 #include "rt_device.h"
 #include "rt_params.h"
 
@@ -105,14 +106,28 @@ struct SceneLds {
     unsigned char* scratch; // kWavesPerWg x kWaveScratch bytes of per-wave work space (pair scan)
 };
 
-template <bool WITH_FB, bool GLOBAL = false>
+// SCENE: 0 = the whole scene copy in the LDS; 1 = nothing staged, every array read from global memory (L2-resident; scenes beyond the LDS);
+//        2 = what every sphere TEST reads (centres, radii^2, group boxes, original indices: 21 bytes per sphere) in the LDS, what only a HIT
+//            reads (colour, type, radius, slot index: 32 bytes per sphere) left in global memory - scenes of 500..1700 spheres keep two
+//            workgroups per CU this way, scenes up to ~5500 spheres stay out of the all-global form.
+template <bool WITH_FB, int SCENE = 0>
 __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigned char* smem, float** after) {
-    if (GLOBAL) {                                                    // the scene does not fit the LDS: read it where it lies (L2-resident)
+    if (SCENE == 1) {                                                // the scene does not fit the LDS: read it where it lies (L2-resident)
         *after = nullptr;
         return { P.spheres, P.groups, P.mat_color, P.mat_type, P.orig, P.slot_of, P.rad, smem };
     }
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
+    if (SCENE == 2) {
+        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups);
+        for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += kThreads) s_sph[k] = P.spheres[k];
+        for (int k = threadIdx.x; k < P.n_padded; k += kThreads) s_org[k] = P.orig[k];
+        for (int k = threadIdx.x; k < 3 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
+        *after = nullptr;
+        unsigned char* scratch = reinterpret_cast<unsigned char*>(s_org + P.n_padded);
+        __syncthreads();
+        return { s_sph, s_grp, P.mat_color, P.mat_type, s_org, P.slot_of, P.rad, scratch };
+    }
     float4* s_mat = s_grp + 3 * P.n_groups;
     int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
     int*    s_org = s_typ + P.n_padded;
@@ -805,10 +820,11 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
 // after it), class 1 "hits something else" (scattered), class 2 "sky" (last) — with one atomic per wave and list.  The
 // lists only change WHO renders a pixel and WHEN, never the result (the seed depends on the pixel id alone).
 // P.queue[4..6] = lengths of the lists.
+template <int SCENE>
 __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSphereParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
-    const SceneLds S = stage_scene<false>(P, smem, &unused);
+    const SceneLds S = stage_scene<false, SCENE>(P, smem, &unused);
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
@@ -985,12 +1001,12 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // sparse form at <= this many live rays.  chain_cfg: bits 0..7 chain waves live in every N-th workgroup; 8..11 chain waves per such
 // workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists; 28..31 pixels a
 // chain wave holds while one of them comes from list 0 (the longest chains).
-//   GLOBAL   the scene is read from global memory instead of an LDS copy (scenes beyond ~2100 spheres)
-template <int PHASE, int CLS, bool CHUNKED, bool DBG, bool GLOBAL = false>
+//   SCENE    where the scene is read from (stage_scene): 0 = an LDS copy, 1 = global memory, 2 = test data in the LDS, hit data in global memory
+template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
-    const SceneLds S = stage_scene<false, GLOBAL>(P, smem, &unused);
+    const SceneLds S = stage_scene<false, SCENE>(P, smem, &unused);
 
     const bool cull = (cfg & 1) != 0;
     const int boost = (cfg >> 8) & 0xFF;
@@ -1292,17 +1308,20 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 }
 }  // namespace
 
-static size_t lds_bytes(int n_padded, int n, bool with_fb) {
-    // spheres + group bounds + material colour + type / original index / radius per slot + slot_of,
+static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0) {
+    // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
-    return (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 +
-           (size_t)n_padded * 16 + (size_t)n_padded * 12 +
-           (size_t)((n + 3) & ~3) * 4 + (with_fb ? (size_t)kThreads * 3 * 4 : 0) + (size_t)kWavesPerWg * kWaveScratch;
+    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48;
+    const size_t scratch = (size_t)kWavesPerWg * kWaveScratch;
+    if (scene == 1) return scratch;
+    if (scene == 2) return test_data + (size_t)n_padded * 4 + scratch;
+    return test_data + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
+           (size_t)((n + 3) & ~3) * 4 + (with_fb ? (size_t)kThreads * 3 * 4 : 0) + scratch;
 }
 
 #if defined(RT_MODE_PARITY)
-size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {
-    return lds_bytes(n_padded, n, false);
+size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {                       // of the smallest LDS-resident form: beyond it the scene is read from global memory
+    return lds_bytes(n_padded, n, false, 2);
 }
 #endif
 
@@ -1318,22 +1337,29 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {
 template <bool CHUNKED>
 static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned blocks, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
     const size_t lds = (size_t)kWavesPerWg * kWaveScratch;          // only the per-wave scratch: the scene stays in global memory
-    hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, true>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, 1>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
     return hipGetLastError();
 }
 
-template <int PHASE, int CLS, bool CHUNKED>
-static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
+template <int PHASE, int CLS, bool CHUNKED, int SCENE>
+static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
     // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
-    const void* kern = q.wave_dbg ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true>)
-                                  : reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false>);
+    const void* kern = q.wave_dbg ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>)
+                                  : reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
-    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
     return hipGetLastError();
+}
+
+// `hybrid`: stage_scene's form 2 (test data in the LDS, hit data in global memory)
+template <int PHASE, int CLS, bool CHUNKED>
+static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, size_t lds, bool hybrid, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
+    return hybrid ? launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 2>(q, blocks, lds, stream, stride, cfg, chain_cfg)
+                  : launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 0>(q, blocks, lds, stream, stride, cfg, chain_cfg);
 }
 
 hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
@@ -1342,7 +1368,12 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
     const bool legacy = cb_bits != 0 && cb_bits != 255;
     if (legacy) kind = 1;                       // the brute-force A/B scans live in the tile kernel only
     if (p.global_scene) kind = 0;               // scenes beyond the LDS: the persistent kernel only
-    const size_t lds = lds_bytes(p.n_padded, p.n, kind == 1);
+    const size_t lds_full = lds_bytes(p.n_padded, p.n, kind == 1), lds_hybrid = lds_bytes(p.n_padded, p.n, false, 2);
+    const size_t kLdsPerCu = 160 * 1024;
+    if (lds_full > kLdsPerCu) kind = 0;         // the tile kernel only knows the full copy
+    // the persistent kernel takes the hybrid copy when that puts more workgroups on a CU (two instead of one: 500..1700 spheres) or when the full one does not fit
+    const bool hybrid = kind == 0 && !p.global_scene && (lds_full > kLdsPerCu || (lds_full > kLdsPerCu / 2 && lds_hybrid <= kLdsPerCu / 2));
+    const size_t lds = hybrid ? lds_hybrid : lds_full;
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
     // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
     const int pb = (variant >> 27) & 7;
@@ -1419,7 +1450,7 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         p.nx <= 65535 && p.part.local_rows <= 65535) {                                   // list entries pack (row << 16 | column)
         RtSphereParams q = p;
         q.phase = 1; q.s_split = split;
-        e = launch_queue_kernel<1, 0, false>(q, nb, lds, stream, stride, cfg, chain_cfg);
+        e = launch_queue_kernel<1, 0, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(p.queue, 0, 256, stream);
         if (e != hipSuccess) return e;
@@ -1428,22 +1459,24 @@ hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stre
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         q.phase = 2;
-        return launch_queue_kernel<2, 2, false>(q, nb, lds, stream, stride, cfg, chain_cfg);
+        return launch_queue_kernel<2, 2, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
     }
     bool classified = false;
     if ((order_mode == 0 || order_mode == 3) && p.order != nullptr) {
+        const void* cls_kern = hybrid ? reinterpret_cast<const void*>(k_classify_spheres<2>) : reinterpret_cast<const void*>(k_classify_spheres<0>);
         if (lds > 64 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_classify_spheres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipFuncSetAttribute(cls_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_classify_spheres, dim3(cls_blocks), dim3(kThreads), lds, stream, p);
+        if (hybrid) hipLaunchKernelGGL(k_classify_spheres<2>, dim3(cls_blocks), dim3(kThreads), lds, stream, p);
+        else hipLaunchKernelGGL(k_classify_spheres<0>, dim3(cls_blocks), dim3(kThreads), lds, stream, p);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         classified = true;
     }
     const bool chunked = p.chunks > 1;
-    if (classified) e = chunked ? launch_queue_kernel<0, 1, true>(p, nb, lds, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 1, false>(p, nb, lds, stream, stride, cfg, chain_cfg);
-    else e = chunked ? launch_queue_kernel<0, 0, true>(p, nb, lds, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 0, false>(p, nb, lds, stream, stride, cfg, chain_cfg);
+    if (classified) e = chunked ? launch_queue_kernel<0, 1, true>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 1, false>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
+    else e = chunked ? launch_queue_kernel<0, 0, true>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 0, false>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
     if (e != hipSuccess) return e;
     if (chunked) {
         const size_t npx = (size_t)p.part.local_rows * p.nx;
