@@ -321,8 +321,47 @@ __device__ __forceinline__ float box_gap(const float4* g3, const BoxRay& r) {
 }
 __device__ __forceinline__ bool box_reach(const float4* g3, const BoxRay& r) { return !(box_gap(g3, r) < 0.0f); }
 
-__device__ __forceinline__ uint32_t group_needs(const SceneLds& S, int g0, int ng, const BoxRay& br, bool cull) {
+template <int I> __device__ __forceinline__ float comp(f3 v) { return I == 0 ? v.x : (I == 1 ? v.y : v.z); }
+template <int I> __device__ __forceinline__ uint32_t bsign(const BoxRay& r) { return I == 0 ? r.sx : (I == 1 ? r.sy : r.sz); }
+
+// The boxes of spheres that rest on a plane (the random-spheres scene: every small sphere has the same height and radius) have the same extent on
+// one axis (found on the host: RtSphereParams::box_shared_axis).  That axis' slab is then the same for every box: evaluated once per pass and
+// folded into the two clamps the test has anyway (t_in against 0, t_out against the closest hit) - 8 instead of 12 instructions per box.
+template <int AX>
+__device__ __forceinline__ uint32_t group_needs_shared(const SceneLds& S, int g0, int ng, const BoxRay& r, float shared_lo, float shared_hi) {
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    constexpr int A1 = (AX + 1) % 3, A2 = (AX + 2) % 3;
+    const float* f = reinterpret_cast<const float*>(S.grp + 3 * g0);
+    const float s_near = bsign<AX>(r) ? shared_hi : shared_lo, s_far = bsign<AX>(r) ? shared_lo : shared_hi;
+    const float in0 = fmaxf(__builtin_fmaf(s_near, comp<AX>(r.inv), -comp<AX>(r.cn)), 0.0f);
+    const float out0 = fminf(__builtin_fmaf(s_far, comp<AX>(r.inv), -comp<AX>(r.cf)), r.cb);
+    const float* f1 = f + 4 * A1 + bsign<A1>(r);
+    const float* f2 = f + 4 * A2 + bsign<A2>(r);
+    uint32_t skip = 0;
+    auto gap = [&](f2u p1, f2u p2) {
+        const float t_in = fmaxf(fmaxf(__builtin_fmaf(p1.x, comp<A1>(r.inv), -comp<A1>(r.cn)), __builtin_fmaf(p2.x, comp<A2>(r.inv), -comp<A2>(r.cn))), in0);
+        const float t_out = fminf(fminf(__builtin_fmaf(p1.y, comp<A1>(r.inv), -comp<A1>(r.cf)), __builtin_fmaf(p2.y, comp<A2>(r.inv), -comp<A2>(r.cf))), out0);
+        return __float_as_uint(t_out - t_in);
+    };
+    // four boxes at a time, their eight LDS reads issued before the first test: one round trip per four boxes instead of one per box
+    int g = 0;
+    for (; g + 4 <= ng; g += 4) {
+        f2u a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = *reinterpret_cast<const f2u*>(f1 + 12 * (g + k)); b[k] = *reinterpret_cast<const f2u*>(f2 + 12 * (g + k)); }
+        __builtin_amdgcn_sched_barrier(0);                           // keep the reads together: the scheduler otherwise re-serialises read -> test
+#pragma unroll
+        for (int k = 0; k < 4; k++) skip = __builtin_amdgcn_alignbit(skip, gap(a[k], b[k]), 31);
+    }
+    for (; g < ng; g++) skip = __builtin_amdgcn_alignbit(skip, gap(*reinterpret_cast<const f2u*>(f1 + 12 * g), *reinterpret_cast<const f2u*>(f2 + 12 * g)), 31);
+    return __brev(~skip << (32 - ng));
+}
+
+__device__ __forceinline__ uint32_t group_needs(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& br, bool cull) {
     if (!cull) return (ng >= 32) ? 0xFFFFFFFFu : ((1u << ng) - 1u);
+    if (P.box_shared_axis == 2) return group_needs_shared<1>(S, g0, ng, br, P.box_shared_lo, P.box_shared_hi);
+    if (P.box_shared_axis == 1) return group_needs_shared<0>(S, g0, ng, br, P.box_shared_lo, P.box_shared_hi);
+    if (P.box_shared_axis == 3) return group_needs_shared<2>(S, g0, ng, br, P.box_shared_lo, P.box_shared_hi);
     // the skip flags are the SIGN BITS of the gaps, shifted in one v_alignbit per box (compare + select + shift + or otherwise);
     // box g of the pass ends up at bit ng - 1 - g: one bit reversal per pass puts it back at bit g
     uint32_t skip = 0;
@@ -444,7 +483,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
         const bool flush = g0 + 2 * kPassGroups - win_base > 1024;
         const bool last_pass = g0 + kPassGroups >= P.n_groups || flush;
-        const uint32_t need = has_ray ? group_needs(S, g0, ng, br, cull) : 0u;
+        const uint32_t need = has_ray ? group_needs(P, S, g0, ng, br, cull) : 0u;
         if (has_ray) boxes_done += (uint32_t)ng;
         // exclusive prefix sum of the pair counts over the wave
         const int cnt = __popc(need);

@@ -51,6 +51,8 @@ struct RtSphereParams {
     // small spheres' centres, k1 = K eps / (2 r_min), k2 = sqrt(K eps), k3 = slab-test rounding per unit of coordinate,
     // coord_max = largest |coordinate| of any group box
     float cull_cx, cull_cy, cull_cz, cull_radius, cull_k1, cull_k2, cull_k3, cull_coord_max;
+    float box_shared_lo, box_shared_hi;   // that extent
+    int32_t box_shared_axis;    // 1 + axis on which every (non-empty) group box has the same extent (spheres resting on a plane), 0 = none: see group_needs
     float pair_k0;              // 2 * kPairSlack * (largest radius of the grouped spheres)^2: see the pair rounds of scan_pairs
     const float4* mat_color;    // n_padded x (r, g, b, param)
     const int32_t* mat_type;    // n_padded

@@ -94,6 +94,8 @@ struct RenderContext {
     std::vector<int32_t> h_mat_type;
     std::vector<float4> h_groups;       // three float4 per group of kSphereGroup slots: per axis (lo, hi, lo, -) of the tight AABB
     float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0, pair_k0 = 0;
+    int box_shared_axis = 0;
+    float box_shared_lo = 0, box_shared_hi = 0;
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
     int n_spheres = 0, n_padded = 0, n_groups = 0, n_big_groups = 0, n_big = 0;
@@ -348,6 +350,9 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     // accepts "hits" of rays that geometrically miss a sphere by more than any fixed inflation - and (b) the rounding of the slab test.
     float coord_max = 0.0f;
     double r_min = 1e300;
+    float shared_lo[3] = { 0, 0, 0 }, shared_hi[3] = { 0, 0, 0 };
+    bool shared_ok[3] = { true, true, true };
+    int n_boxes = 0;
     for (int g = n_big_groups; g < c.n_groups; g++) {
         double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
         int cnt = 0;
@@ -368,7 +373,14 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
             coord_max = std::max(coord_max, std::max(fabsf(flo[a]), fabsf(fhi[a])));
         }
         for (int a = 0; a < 3; a++) c.h_groups[3 * g + a] = make_float4(flo[a], fhi[a], flo[a], 0.0f);
+        for (int a = 0; a < 3; a++) {                                // an axis on which every group box has the same extent?
+            if (n_boxes == 0) { shared_lo[a] = flo[a]; shared_hi[a] = fhi[a]; }
+            else if (shared_lo[a] != flo[a] || shared_hi[a] != fhi[a]) shared_ok[a] = false;
+        }
+        n_boxes++;
     }
+    c.box_shared_axis = 0;
+    for (int a = 2; a >= 0; a--) if (n_boxes > 0 && shared_ok[a]) { c.box_shared_axis = a + 1; c.box_shared_lo = shared_lo[a]; c.box_shared_hi = shared_hi[a]; }
     // per-ray margin constants
     double cc[3] = { 0, 0, 0 }, rad = 0.0;
     if (!small.empty()) {
@@ -548,7 +560,7 @@ void runRenderer(int ns, int tx, int ty) {
             p.spheres = d.d_spheres; p.rad = d.d_rad; p.global_scene = c.global_scene; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
-            p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max; p.pair_k0 = c.pair_k0;
+            p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max; p.pair_k0 = c.pair_k0; p.box_shared_axis = c.box_shared_axis; p.box_shared_lo = c.box_shared_lo; p.box_shared_hi = c.box_shared_hi;
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
