@@ -631,7 +631,10 @@ __device__ __forceinline__ void sparse_test_slot(const RtSphereParams& P, const 
 // a lane fetches the ray of its item from the wave's LDS ray table.  Two rays therefore cost three lane passes like one
 // ray does (16 + 16 big slots, 31 + 31 boxes, ~2 x 16 spheres), where handling the rays one after the other cost six.
 __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, unsigned long long live,
-                                           bool cull) {
+                                           bool cull, unsigned long long* tm = nullptr) {
+    // tm (diagnostic instantiation only): cycles in [10] ray table + box set-up, [11] big spheres, [12] group boxes, [13] sphere tests + read-back
+    unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
     float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r at w_ray[2r], w_ray[2r + 1]
@@ -652,6 +655,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    lap(10);
     // (a) big spheres: items (ray, slot)
     const int nbs = P.n_big_groups << kSphereGroupShift;
     for (int base = 0; base < m * nbs; base += 64) {
@@ -664,6 +668,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    lap(11);
     // (b) group boxes: items (ray, group); the reachable ones are appended to the pair list
     const int ng = P.n_groups - P.n_big_groups;
     int np = 0;                                                      // pairs in the list (wave-uniform)
@@ -695,6 +700,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    lap(12);
     // (c) the spheres of the reachable pairs: items (pair, sphere of the group)
     for (int base = 0; base < (np << kSphereGroupShift); base += 64) {
         const int w = base + lane;
@@ -716,6 +722,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
             out.sid = S.slot_of[out.orig];
         }
     }
+    lap(13);
     return out;
 }
 
@@ -772,7 +779,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
         // (the sparse form lists its reachable (ray, group) pairs in the wave's pair list: rays x groups must fit it)
         if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && P.n_groups <= 4096 &&
-            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap) { h = scan_sparse(P, S, L.org, dn, a, live, cull); lap(6); }
+            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap) { h = scan_sparse(P, S, L.org, dn, a, live, cull, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
         else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
@@ -1112,9 +1119,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     // their SGPR pressure): 100 MHz time stamps and iteration counts of this wave
     unsigned long long* const wdbg = DBG ? P.wave_dbg : nullptr;
     const unsigned long long dbg_t0 = wdbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long dbg_t0c = wdbg ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long dbg_tex = 0ull;
     uint32_t dbg_iters = 0, dbg_coop_iters = 0, dbg_coop_rays = 0, dbg_maxpix = 0;
-    unsigned long long dbg_tm[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // section cycles (see trace_rays), [7] refill, [8]/[9] main / boost steps
+    unsigned long long dbg_tm[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // section cycles (see trace_rays), [7] refill, [8]/[9] main / boost steps
     float dbg_grab = 0.0f, dbg_p1 = 0.0f;                           // this lane's pixel: time it was grabbed, rays of phase 1
 
     // end of a path for the lanes in `fin`: accumulate, start the next sample, or store the finished pixel
@@ -1327,6 +1335,12 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         w[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
         w[7] = 1;
         for (int k = 0; k < 8; k++) atomicAdd(wdbg + 65534ull * 8 + k, dbg_tm[k]);      // section cycles, summed over the waves
+        if (dbg_coop_iters >= 2000ull) {                                                // the same for the waves that carry the longest chains, + the sparse form's phases
+            for (int k = 0; k < 8; k++) atomicAdd(wdbg + 65532ull * 8 + k, dbg_tm[k]);
+            for (int k = 0; k < 4; k++) atomicAdd(wdbg + 65531ull * 8 + k, dbg_tm[10 + k]);
+            atomicAdd(wdbg + 65531ull * 8 + 4, dbg_coop_iters); atomicAdd(wdbg + 65531ull * 8 + 5, 1ull);
+            atomicAdd(wdbg + 65531ull * 8 + 6, __builtin_amdgcn_s_memtime() - dbg_t0c);
+        }
         atomicAdd(wdbg + 65533ull * 8 + 0, dbg_tm[8]); atomicAdd(wdbg + 65533ull * 8 + 1, dbg_tm[9]);
     }
 }

@@ -3,7 +3,8 @@ import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
 sec, steps = a[65534].astype(np.float64), a[65533].astype(np.float64)
-a = a[:65533]
+csec, cspa = a[65532].astype(np.float64), a[65531].astype(np.float64)     # the same for the waves with >= 2000 sparse-form iterations
+a = a[:65531]
 a = a[a[:, 7] == 1]
 t0 = a[:, 0].min()
 start = (a[:, 0] - t0) / 1e5      # ms (100 MHz)
@@ -45,3 +46,12 @@ if sec.sum() > 0:
     for n_, c in zip(names, sec):
         print("  %-30s %5.1f %%" % (n_, 100 * c / sec.sum()))
     print("  main steps %.3g, boost steps %.3g" % (steps[0], steps[1]))
+
+if csec.sum() > 0 and cspa[5] > 0:
+    names = ["ray set-up (unit dir)", "big spheres (dense)", "group boxes + pair list (dense)", "pair rounds (dense)", "candidates (dense)", "shade", "sparse scan (old slot)", "refill / start pixel+sample"]
+    tot = cspa[6]
+    print("waves with >= 2000 sparse-form iterations: %d, %.0f iterations each, %.0f cycles of wave life per iteration" % (cspa[5], cspa[4] / cspa[5], tot / cspa[4]))
+    for n_, c in zip(names, csec):
+        print("  %-34s %5.1f %% of their life" % (n_, 100 * c / tot))
+    for n_, c in zip(["sparse: ray table + box set-up", "sparse: big spheres", "sparse: group boxes", "sparse: sphere tests + read-back"], cspa[:4]):
+        print("  %-34s %5.1f %% of their life" % (n_, 100 * c / tot))
