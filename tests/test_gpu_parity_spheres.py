@@ -212,6 +212,31 @@ def test_arbitrary_sphere_scenes_bit_exact(rt, O, n, big, dup):
         assert st.rays == cnt.rays
 
 
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_spheres_on_a_plane_share_a_box_slab(rt, O, axis):
+    """Equal spheres whose centres lie in a plane normal to `axis`: every group box has the same extent on that axis, which the kernel
+    then evaluates once per pass (group_needs_shared<AX>, one instantiation per axis; random scenes take the general loop)."""
+    rng = np.random.default_rng(77 + axis)
+    n = 200
+    sp = np.zeros(n, rt.sphere_dtype)
+    mt = np.zeros(n, rt.material_dtype)
+    c = rng.uniform(-5, 5, (n, 3))
+    c[:, axis] = 0.25
+    sp["center"] = c
+    sp["radius"] = 0.25
+    sp["center"][0] = (0, -500.5, 0); sp["radius"][0] = 500               # one big sphere: handled apart, does not break the shared extent
+    mt["type"] = rng.integers(0, 3, n)
+    mt["color"] = rng.uniform(0.1, 1, (n, 3))
+    mt["param"] = np.where(mt["type"] == rt.RT_GLASS, 1.5, rng.uniform(0, 0.3, n))
+    mt["texId"] = -1
+    nx, ny, ns = 96, 64, 3
+    cam = rt.make_camera((9, 3, 7), (0, 0, 0), (0, 1, 0), 35.0, nx / ny, 0.05, 10.0)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 20, counters=True)
+    got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 20, counters=1, variant=0)
+    assert np.array_equal(_bits(got), _bits(ref)), np.count_nonzero(_bits(got) != _bits(ref))
+    assert st.rays == cnt.rays
+
+
 def test_camera_inside_scene_and_odd_image_sizes(rt, O):
     """Camera inside the sphere cloud (rays start inside group boxes), image sizes that are not multiples of 8."""
     rng = np.random.default_rng(77)
