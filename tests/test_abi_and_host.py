@@ -229,3 +229,42 @@ def test_committed_traffic_matches_the_committed_kernel_sources():
     if not os.path.exists(p):
         pytest.skip("no committed traffic measurement")
     assert json.load(open(p))["kernel_source_hash"] == bench.kernel_source_hash()
+
+
+def test_pair_round_pretest_flags_every_positive_discriminant():
+    """The sphere kernel's pair rounds FIND the spheres with a positive discriminant with fused multiply-adds and a slack (DESIGN.md 3.5, v9;
+    rt_kernels_spheres.hip scan_pairs): v = (a - k) c_fma - (b_fma^2 + k0) must be negative whenever the reference's own evaluation
+    (intersections.h:88-93, every product and sum rounded to fp32) has b*b - a*c > 0.  Emulated here in numpy - fp32 operations as float32
+    arithmetic, a fused multiply-add as the float64 result rounded once (products of two fp32 numbers are exact in float64) - on random
+    and on near-tangent rays, far and near, with the kernel's constants."""
+    f32 = np.float32
+    rng = np.random.default_rng(11)
+    n = 400000
+    k = f32(2.0 ** -18)
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+    for dist, r_max in ((3.0, 0.3), (40.0, 0.3), (3000.0, 0.3), (1.0, 0.9)):
+        r = rng.uniform(0.05, r_max, n).astype(f32)
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d = d.astype(f32)
+        # centres placed so that the ray (origin 0) passes at a distance of r (1 + tiny) from them: the discriminant is ~0 for half of the set
+        along = rng.uniform(0.2, 1.0, n) * dist
+        perp = rng.normal(size=(n, 3)); perp -= (perp * d).sum(1, keepdims=True) * d; perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+        tangent = rng.random(n) < 0.5
+        miss = np.where(tangent, 1.0 + rng.normal(scale=3e-7, size=n), rng.uniform(0.0, 2.0, n))
+        centre = (d * along[:, None] + perp * (r * miss)[:, None]).astype(f32)
+        oc = (f32(0) - centre).astype(f32)                                              # o - centre, o = 0
+        a = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(f32) + d[:, 2] * d[:, 2]).astype(f32)
+        b = ((oc[:, 0] * d[:, 0] + oc[:, 1] * d[:, 1]).astype(f32) + oc[:, 2] * d[:, 2]).astype(f32)
+        c = (((oc[:, 0] * oc[:, 0] + oc[:, 1] * oc[:, 1]).astype(f32) + oc[:, 2] * oc[:, 2]).astype(f32) - (r * r).astype(f32)).astype(f32)
+        disc = ((b * b).astype(f32) - (a * c).astype(f32)).astype(f32)
+        positive = disc > 0
+        r2 = (r * r).astype(f32)
+        bf = fma(oc[:, 2], d[:, 2], fma(oc[:, 1], d[:, 1], (oc[:, 0] * d[:, 0]).astype(f32)))
+        cf = fma(oc[:, 2], oc[:, 2], fma(oc[:, 1], oc[:, 1], fma(oc[:, 0], oc[:, 0], -r2)))
+        k0 = f32(2.0 * 3.814697265625e-6 * float(r_max) ** 2 * 1.0001)
+        v = fma((a - k).astype(f32), cf, -fma(bf, bf, np.full(n, k0, f32)))
+        assert positive.sum() > n // 10 and (~positive).sum() > n // 10
+        assert np.all(v[positive] < 0), (dist, int(np.count_nonzero(v[positive] >= 0)))
+        if dist <= 40.0:                                                                # (far away the slack, like the reference's own rounding noise, exceeds r^2:
+            assert np.count_nonzero((v < 0) & ~positive & ~tangent) < n // 20           #  everything is flagged there) - near, away from tangency, little else is
