@@ -162,7 +162,9 @@ struct Lane {
 };
 
 // kernels.cu:549-555 + the head of color() :397-398: starts sample L.s of the lane's pixel
-__device__ __forceinline__ void start_sample(const RtSphereParams& P, Lane& L) {
+struct SampleParams { rt_camera cam; int32_t nx, ny, rng_mode; };     // what start_sample reads of the kernel parameters
+template <typename PP>
+__device__ __forceinline__ void start_sample(const PP& P, Lane& L) {
     if (P.rng_mode == RT_RNG_COUNTER) L.rng = sample_seed(L.pixelId, (uint32_t)L.s);
     const float u = ((float)L.i + rnd(L.rng)) / (float)P.nx;
     const float v = ((float)L.j + rnd(L.rng)) / (float)P.ny;
@@ -1115,6 +1117,22 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     bool exhausted = false;             // wave-uniform: the global queue is empty
     uint32_t pool_next = 0, pool_end = 0;   // wave-uniform: the wave's reserved queue positions [pool_next, pool_end)
     float* fbf = reinterpret_cast<float*>(P.fb);
+    // Parameters read once per sample are NOT kept in SGPRs for the life of the wave (the camera alone is 22 of them, spilled to VGPR lanes):
+    // they are re-read from the device copy of the parameter block through a pointer the optimiser cannot see through (scalar loads, cached).
+    auto sample_params = [&]() {
+        typedef const __attribute__((address_space(4))) float* ColdF;
+        typedef const __attribute__((address_space(4))) int32_t* ColdI;
+        unsigned long long base = (unsigned long long)P.self;
+        asm volatile("" : "+s"(base));
+        SampleParams sp;
+        ColdF cf = (ColdF)(base + offsetof(RtSphereParams, cam));
+        float* dst = reinterpret_cast<float*>(&sp.cam);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(rt_camera) / 4); k++) dst[k] = cf[k];
+        sp.nx = *(ColdI)(base + offsetof(RtSphereParams, nx)); sp.ny = *(ColdI)(base + offsetof(RtSphereParams, ny));
+        sp.rng_mode = *(ColdI)(base + offsetof(RtSphereParams, rng_mode));
+        return sp;
+    };
     // diagnostics (only when wdbg, and only in the DBG instantiation: in the production one they compile away, with
     // their SGPR pressure): 100 MHz time stamps and iteration counts of this wave
     unsigned long long* const wdbg = DBG ? P.wave_dbg : nullptr;
@@ -1136,7 +1154,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
             if (L.s < s_end) {
-                if (now) start_sample(P, L); else need_sample = true;
+                if (now) start_sample(sample_params(), L); else need_sample = true;
             } else {
                 if (PHASE == 1) {                                    // first samples done: park the pixel (RNG state, running sum, cost)
                     const size_t px = (size_t)lr * P.nx + L.i;
@@ -1280,7 +1298,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 }
             }
         }
-        if (need_sample) { start_sample(P, L); need_sample = false; }
+        if (need_sample) { start_sample(sample_params(), L); need_sample = false; }
         const unsigned long long live_now = __ballot(have_pixel);
         if (DBG && wdbg) dbg_tm[7] += __builtin_amdgcn_s_memtime() - t_refill;
         if (live_now == 0ull) break;                                 // wave-uniform exit: idle lanes stay to help
@@ -1415,7 +1433,23 @@ static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, 
                   : launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 0>(q, blocks, lds, stream, stride, cfg, chain_cfg);
 }
 
-hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
+static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream);
+
+hipError_t RT_LAUNCH_NAME(const RtSphereParams& p_in, int variant, hipStream_t stream) {
+    // the device copy of the parameter block (RtSphereParams::self): one per device, refreshed by every launch
+    static RtSphereParams* dev_copy[16] = { nullptr };
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!dev_copy[dev]) { const hipError_t e = hipMalloc((void**)&dev_copy[dev], sizeof(RtSphereParams)); if (e != hipSuccess) return e; }
+    RtSphereParams p = p_in;
+    p.self = dev_copy[dev];
+    const hipError_t e = hipMemcpyAsync(dev_copy[dev], &p, sizeof p, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    return launch_spheres(p, variant, stream);
+}
+
+static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream) {
     int kind = variant & 0xFF;
     const int cb_bits = (variant >> 16) & 0xFF;
     const bool legacy = cb_bits != 0 && cb_bits != 255;
