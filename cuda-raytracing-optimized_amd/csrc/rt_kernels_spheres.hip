@@ -1436,7 +1436,10 @@ static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, 
 static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream);
 
 hipError_t RT_LAUNCH_NAME(const RtSphereParams& p_in, int variant, hipStream_t stream) {
-    // the device copy of the parameter block (RtSphereParams::self): one per device, refreshed by every launch
+    // the device copy of the parameter block (RtSphereParams::self): one per device, refreshed by every launch.  Only fields that are the same for
+    // every partition of a frame (camera, image size, RNG mode) may be read through it: partitions rendered on ONE device by several streams (the
+    // in-process multi-device path on a single GPU) share the copy.  (Reading the per-pixel fields - framebuffer, parked state, partition - this way
+    // too took the kernel from 61 to 43 spilled SGPRs and gained nothing more: 7030 against 7025 Msamples/s.)
     static RtSphereParams* dev_copy[16] = { nullptr };
     int dev = 0;
     (void)hipGetDevice(&dev);
