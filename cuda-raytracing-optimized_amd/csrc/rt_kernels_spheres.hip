@@ -1164,7 +1164,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     const f3 out = L.col / (float)P.ns;              // kernels.cu:568
                     // one 12-byte store (global_store_dwordx3): a lane finishes its pixel on its own, so three dword
                     // stores would be three partial-sector writes
-                    *reinterpret_cast<float3*>(fbf + ((size_t)lr * P.nx + L.i) * 3) = make_float3(out.x, out.y, out.z);
+                    *reinterpret_cast<float3*>(fbf + ((size_t)(P.fb_global_rows ? L.j : lr) * P.nx + L.i) * 3) = make_float3(out.x, out.y, out.z);
                 } else {                                             // partial sum of this chunk; k_sum_chunks adds them in order
                     float* dst = reinterpret_cast<float*>(P.partial) + (((size_t)lr * P.nx + L.i) * (uint32_t)P.chunks + (uint32_t)chunk) * 3;
                     dst[0] = L.col.x; dst[1] = L.col.y; dst[2] = L.col.z;

@@ -550,6 +550,7 @@ void runRenderer(int ns, int tx, int ty) {
         // frame, so a pixel the work distribution lost shows up as NaN instead of as last frame's (correct-looking) value.
         if (d.fb_rows > 0) HIP_CHECK(hipMemsetAsync(d.d_fb, 0xFF, d.fb_rows * row_bytes, d.stream));
         HIP_CHECK(hipEventRecord(d.ev_start, d.stream));
+        bool fb_direct = false;
         if (c.max_depth <= 0) {
             HIP_CHECK(hipMemsetAsync(d.d_fb, 0, d.fb_rows * row_bytes, d.stream));     // loop of kernels.cu:402 never runs
         } else if (c.is_spheres) {
@@ -592,6 +593,17 @@ void runRenderer(int ns, int tx, int ty) {
             }
             if (c.opt.nee) rt_fail("runRenderer: next-event estimation is only defined for mesh scenes");
             if (c.opt.floor) rt_fail("runRenderer: the floor plane is only defined for mesh scenes (kernel_scene.floor)");
+            // Finished pixels go straight to the pinned host framebuffer (12 bytes each, spread over the whole frame time) when the default kernel
+            // writes them itself: no device-to-host copy after the kernel.  RT_FB_DIRECT=0 keeps the compact device buffer + copy.
+            static const bool fb_direct_env = !(getenv("RT_FB_DIRECT") && getenv("RT_FB_DIRECT")[0] == '0');
+            const int vk = c.opt.variant & 0xFF, vcb = (c.opt.variant >> 16) & 0xFF;
+            fb_direct = fb_direct_env && vk == 0 && (vcb == 0 || vcb == 255) && p.chunks == 1;
+            if (fb_direct) {
+                void* dp = nullptr;
+                HIP_CHECK(hipHostGetDevicePointer(&dp, c.h_ext ? (void*)c.h_ext : (void*)c.h_fb, 0));
+                p.fb = reinterpret_cast<rt_vec3*>(dp);
+                p.fb_global_rows = 1;
+            }
             HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream)
                                              : rt_launch_spheres_parity(p, c.opt.variant, d.stream));
             launches++;
@@ -629,10 +641,10 @@ void runRenderer(int ns, int tx, int ty) {
         const size_t full = d.fb_rows / sr, rem = d.fb_rows % sr;
         char* dst0 = reinterpret_cast<char*>(c.h_ext ? c.h_ext : c.h_fb) + (size_t)part.rank * stripe_bytes;
         const char* src0 = reinterpret_cast<const char*>(d.d_fb);
-        if (full > 0)
+        if (full > 0 && !fb_direct)
             HIP_CHECK(hipMemcpy2DAsync(dst0, (size_t)world * stripe_bytes, src0, stripe_bytes, stripe_bytes, full,
                                        hipMemcpyDeviceToHost, d.stream));
-        if (rem > 0)
+        if (rem > 0 && !fb_direct)
             HIP_CHECK(hipMemcpyAsync(dst0 + full * (size_t)world * stripe_bytes, src0 + full * stripe_bytes, rem * row_bytes,
                                      hipMemcpyDeviceToHost, d.stream));
         samples += (int64_t)d.fb_rows * c.nx * ns;
