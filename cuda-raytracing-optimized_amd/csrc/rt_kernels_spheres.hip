@@ -14,10 +14,10 @@
 //     of their pixel instead of at every short path (the reference's warp efficiency was 41 %);
 //   * the sphere array (cx,cy,cz,r*r) and the materials are staged once per workgroup into LDS
 //     (instead of __constant__); the scan reads them with wave-uniform ds_read_b128 broadcasts;
-//   * the closest-hit scan is split in two phases.  Phase 1 evaluates only the sign of the
-//     discriminant for 32 spheres at a time (17 VALU ops/sphere, no branch, no compare: the sign
-//     bit is shifted into a per-lane 32-bit mask with one v_alignbit).  Phase 2 walks the set bits
-//     in index order and runs the full sphereHit (IEEE sqrt + divide) only for those candidates.
+//   * the closest-hit scan is split in two phases.  Phase 1 FINDS the spheres whose discriminant is positive: fused multiply-adds
+//     and a proven slack (12 VALU ops/sphere, no branch, no compare: the sign bit is shifted into a per-lane mask with one
+//     v_alignbit; every sphere the reference's own arithmetic accepts is flagged).  Phase 2 runs the literal sphereHit
+//     (every product and sum rounded, IEEE sqrt + divide) only for those candidates.
 //     Because a non-candidate returns FLT_MAX in the reference and never updates `closest`, and
 //     candidates are visited in increasing index with the same strict `<`, the result is
 //     bit-identical to the reference's linear scan;
@@ -27,9 +27,12 @@
 //     exact for any ray origin), and the (ray, group) pairs of a wave are compacted so that all 64 lanes always work.
 //     A skipped sphere could only have produced t > closest (rejected by the reference) or FLT_MAX, so the result
 //     is unchanged; the explicit (t, original index) tie rule keeps the reference's first-index-wins order;
+//   * the group boxes are stored per AXIS as (lo, hi, lo): a ray reads (near, far) at an offset given by the sign of its direction; an axis on
+//     which all boxes agree (spheres on a plane) is evaluated once per pass; results are accumulated as sign bits (box_gap, group_needs);
 //   * framebuffer: the persistent kernels (default) store a finished pixel with ONE 12-byte store from the lane that owns it
-//     (pixels finish one by one, in cost order); only the tile kernel (variant 1) transposes its 8x8 tile through LDS so that a
-//     wave writes row-contiguous dwords;
+//     (pixels finish one by one, in cost order) - by default straight into the pinned host framebuffer (RtSphereParams::fb_global_rows);
+//     only the tile kernel (variant 1) transposes its 8x8 tile through LDS so that a wave writes row-contiguous dwords;
+//   * parameters needed once per sample (camera, image size) are re-read from a device copy of the parameter block (RtSphereParams::self);
 //   * the scene copy of a workgroup comes in three forms (stage_scene, template parameter SCENE): everything in the LDS; the test data in the LDS and the
 //     hit data in global memory (two workgroups per CU up to ~1500 spheres, LDS-resident up to ~5000); everything read from global memory beyond that.
 #include "rt_device.h"
