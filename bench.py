@@ -122,10 +122,11 @@ class HipBackend:
                             rng=rt.RT_RNG_COUNTER if self.rng == "counter" else rt.RT_RNG_REFERENCE_STREAM,
                             variant=self.variant, part_rank=rank, part_world=world, stripe_rows=8)
         if shared_fb is not None:
-            rt.setExternalFramebuffer(shared_fb)     # every rank's D2H stripe copies land in the one shared framebuffer
+            rt.setExternalFramebuffer(shared_fb)     # every rank delivers its stripes into the one shared framebuffer (finished pixels are stored
+                                                     # straight into it over the bus; the kernels without direct delivery copy their stripes into it)
 
     def step(self, spp=None):
-        self.rt.runRenderer(spp or self.w["spp"], 8, 8)      # blocking: kernel(s) + D2H of this rank's stripes = the host gather
+        self.rt.runRenderer(spp or self.w["spp"], 8, 8)      # blocking: kernel(s) incl. the delivery of this rank's stripes = the host gather
         return self.rt.getRenderStats().kernel_ms
 
     def counted(self, spp):
@@ -196,24 +197,30 @@ def run_job(backend, comm, w, steps, warmup, tag="job", count_spp=None, warmup_s
 
 
 def sphere_roofline(job, world, traffic=None):
-    """fp32 VALU roofline of the sphere kernel, per launch on one GPU."""
+    """fp32 VALU roofline of the sphere kernel, per launch on one GPU.
+
+    `frac` = flops the kernel EXECUTES / kernel time / peak: 18 x executed sphere tests + 20 x group-box tests + 80 x rays, all three counted on
+    the device (an untimed run of the same frame with the counters on; the ray count equals the oracle's).  It cannot exceed 1.
+    `effective_frac` is SURVEY.md §8d's figure - the flops the reference's brute-force scan would need for the same rays, rays x (18 x 488 + 80),
+    over the same time: a rate of useful work, not of hardware use (the exact culling executes ~33 of the 488 tests per ray), and it may
+    exceed 1 (it does on C5)."""
     c = job["counters"]
     rays = c["rays"] / world
-    flops = rays * (FLOPS_PER_TEST * N_SPHERES + FLOPS_PER_RAY)
-    achieved = flops / (job["kernel_ms"] * 1e-3) / 1e12
+    eff_flops = rays * (FLOPS_PER_TEST * N_SPHERES + FLOPS_PER_RAY)
+    eff = eff_flops / (job["kernel_ms"] * 1e-3) / 1e12
     ex_flops = (FLOPS_PER_TEST * c["exec_tests"] + FLOPS_PER_BOX * c["box_tests"] + FLOPS_PER_RAY * c["rays"]) / world
     ex = ex_flops / (job["kernel_ms"] * 1e-3) / 1e12
-    r = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-         "frac_definition": "ALGORITHMIC flops of the reference's brute-force scan (SURVEY.md §8d: rays x (18 x 488 + 80), rays counted on the "
-                            "GPU, bit-equal to the oracle's count) / kernel time / peak: an EFFECTIVE rate, not hardware utilisation",
-         "effective_frac": achieved / PEAK_FP32_VALU_TFLOPS,
-         "executed": {"tflops": ex, "frac": ex / PEAK_FP32_VALU_TFLOPS,
-                      "definition": "flops the kernel actually executes: 18 x executed sphere tests + 20 x group/node box tests + 80 x rays "
-                                    "(device counters) / kernel time; the exact culling executes exec_tests_per_ray of the 488 tests per ray",
-                      "exec_tests_per_ray": job["exec_tests_per_ray"],
-                      "box_tests_per_ray": (c["box_tests"] / c["rays"]) if c["rays"] else None},
-         "kernel": "k_render_spheres_queue", "kernel_ms_avg": job["kernel_ms"], "flops_per_launch": flops,
+    r = {"bound": "valu", "achieved": ex, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+         "frac": ex / PEAK_FP32_VALU_TFLOPS,
+         "frac_definition": "EXECUTED flops / kernel time / peak: 18 x executed sphere tests + 20 x group-box tests + 80 x rays (device counters of "
+                            "an untimed run of the same frame, scaled by spp; rays equal the oracle's count)",
+         "flops_per_launch": ex_flops,
+         "executed_per_ray": {"sphere_tests": job["exec_tests_per_ray"], "box_tests": (c["box_tests"] / c["rays"]) if c["rays"] else None,
+                              "of_spheres": N_SPHERES},
+         "effective_frac": eff / PEAK_FP32_VALU_TFLOPS, "effective_tflops": eff, "effective_flops_per_launch": eff_flops,
+         "effective_definition": "SURVEY.md §8d: the reference's brute-force scan for the same rays, rays x (18 x 488 + 80) flops, over the same "
+                                 "kernel time - useful work per second, NOT hardware utilisation (may exceed 1)",
+         "kernel": "k_render_spheres_queue", "kernel_ms_avg": job["kernel_ms"],
          "algorithmic_hbm_bytes": job["nx"] * job["ny"] * 12,
          "note": "one frame = one 'launch': with the reference RNG stream the persistent kernel is dispatched twice per frame (first 2 samples, then "
                  "the cost-ordered rest) and kernel_ms_avg is the HIP-event time over both. fp32 VALU bound: no GEMM shape, no MFMA (157.3 TFLOP/s "
@@ -272,9 +279,12 @@ def committed_traffic(config, algorithmic_bytes):
     e = t.get(config)
     if not e:
         return {"traffic": None, "traffic_source": f"profiles/traffic.json has no entry for {config}"}
-    return {"traffic": e["bytes_per_frame"], "traffic_unit": "bytes/frame", "traffic_over_algorithmic": e["bytes_per_frame"] / algorithmic_bytes,
-            "traffic_source": f"committed_profile: profiles/traffic.json ({e.get('how', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2')}), "
-                              f"kernel sources {t['kernel_source_hash']}"}
+    out = {"traffic": e["bytes_per_frame"], "traffic_unit": "bytes/frame", "traffic_over_algorithmic": e["bytes_per_frame"] / algorithmic_bytes,
+           "traffic_source": f"committed_profile: profiles/traffic.json ({e.get('how', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2')}), "
+                             f"kernel sources {t['kernel_source_hash']}"}
+    if e.get("pmc"):          # the hardware's own view of the same frame (SQ counters of the committed PMC passes; profiles/<tag>_<config>_summary.txt)
+        out["hardware"] = e["pmc"]
+    return out
 
 
 def cpu_baseline(w):
@@ -376,7 +386,7 @@ def main():
             # C3: the same frame at 1000 spp
             j3 = run_job(hip, comm, WORKLOADS["C3"], 2, 1, tag, count_spp=8, warmup_spp=16)
             others["C3"] = brief(j3, {"workload": WORKLOADS["C3"]["name"] + ", " + mode,
-                                      "roofline": {k: v for k, v in sphere_roofline(j3, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "executed", "traffic")}})
+                                      "roofline": {k: v for k, v in sphere_roofline(j3, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic")}})
             # C4: triangle mesh + BVH through the reference's own entry point
             j4 = run_job(HipBackend(args.fp, "reference", 0), comm, WORKLOADS["C4"], 2, 1, tag, count_spp=4, warmup_spp=16)
             w4 = WORKLOADS["C4"]
@@ -385,7 +395,7 @@ def main():
             # C5's workload on this one GPU (the denominator of the N > 1 strong-scaling lines)
             j5 = run_job(hip, comm, WORKLOADS["C5"], 1, 1, tag, count_spp=4, warmup_spp=16)
             others["C5_one_gpu"] = brief(j5, {"workload": WORKLOADS["C5"]["name"] + ", " + mode + "; the whole frame on ONE GPU",
-                                              "roofline": {k: v for k, v in sphere_roofline(j5, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "executed", "traffic")}})
+                                              "roofline": {k: v for k, v in sphere_roofline(j5, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic")}})
     else:
         w = with_overrides(WORKLOADS["C5"])
         job = run_job(hip, comm, w, args.steps, args.warmup, tag, count_spp=4, warmup_spp=16)

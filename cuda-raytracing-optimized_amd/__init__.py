@@ -129,7 +129,10 @@ assert triangle_dtype.itemsize == 64 and bvh_node_dtype.itemsize == 24
 # symbols every library must export (tests check the .so against the headers with these)
 RENDERER_SYMBOLS = ["initRenderer", "runRenderer", "cleanupRenderer", "initRendererSpheres",
                     "getDefaultRenderOptions", "setRenderOptions", "setExternalFramebuffer", "getRenderStats",
-                    "rtDeviceCount", "rtApiVersion"]
+                    "rtDeviceCount", "rtApiVersion", "rtStructSizes"]
+RT_API_VERSION = 1002       # include/rt_api.h: the version this mirror was written against
+# the structs that cross the C-ABI, in the order of the RT_SIZEOF_* indices of include/rt_api.h
+ABI_STRUCTS = [render_options, render_stats, camera, sphere, material, triangle, bvh_node, mesh, kernel_scene, stexture, plane, bbox, vec3]
 HOST_SYMBOLS = ["rtMakeCamera", "rtRandomFloat", "rtSceneThreeSpheres", "rtSceneRandomSpheres", "rtStaircaseCamera",
                 "rtBuildBvh", "rtBuildBvhLevels", "rtLoadBvhFile", "rtSaveBvhFile", "rtFreeMesh", "rtMeshView",
                 "rtSceneStaircaseProcedural", "rtLinearToSRGB", "rtWritePPM", "rtSaveReference", "rtLoadReference", "rtRmse"]
@@ -184,6 +187,30 @@ def load_host():
     return _host
 
 
+def check_abi(lib, path=RENDERER_LIB, structs=None):
+    """Version + struct-size handshake with a loaded librt_mi355x.so.  getDefaultRenderOptions / getRenderStats write sizeof(struct) bytes
+    through the caller's pointer: a mirror of another generation than the library must be an ImportError here, not a heap overrun there
+    (what the round-2 crash was: a rebuilt library beside a stale mirror)."""
+    structs = ABI_STRUCTS if structs is None else structs
+    if not hasattr(lib, "rtStructSizes"):
+        raise ImportError(f"{path} predates the ABI handshake (no rtStructSizes): rebuild it with `make`")
+    lib.rtApiVersion.argtypes = []
+    lib.rtApiVersion.restype = C.c_int
+    lib.rtStructSizes.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    lib.rtStructSizes.restype = C.c_int
+    ver = lib.rtApiVersion()
+    if ver != RT_API_VERSION:
+        raise ImportError(f"{path} has API version {ver}, this binding was written against {RT_API_VERSION}: rebuild the library or update the mirror")
+    out = (C.c_int32 * len(structs))()
+    n = lib.rtStructSizes(out, len(structs))
+    if n != len(structs):
+        raise ImportError(f"{path} reports {n} ABI structs, the mirror has {len(structs)}")
+    for t, sz in zip(structs, out):
+        if C.sizeof(t) != sz:
+            raise ImportError(f"{path}: sizeof({t.__name__}) is {sz} in the library and {C.sizeof(t)} in the Python mirror - "
+                              "library and mirror are of different generations; refusing to call into it")
+
+
 def load_renderer():
     """librt_mi355x.so — the HIP renderer.  Raises ImportError if it is not built: there is no fallback."""
     global _renderer
@@ -192,6 +219,7 @@ def load_renderer():
             raise ImportError(f"{RENDERER_LIB} is not built: run `make` (or __graft_entry__.build()); "
                               "there is no CPU fallback for the render path")
         r = C.CDLL(RENDERER_LIB)
+        check_abi(r)
         r.initRenderer.argtypes = [kernel_scene, camera, C.POINTER(C.POINTER(vec3)), C.c_int, C.c_int, C.c_int]
         r.initRenderer.restype = None
         r.runRenderer.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -459,7 +487,7 @@ def rmse(f, g):
 # per-function device probes (include/rt_probe.h)
 # ---------------------------------------------------------------------------------------------
 
-PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math", "ShadowRay", "PlaneHit")
+PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math", "ShadowRay", "PlaneHit", "SinCos")
                  for m in ("parity", "fast")]
 
 
@@ -550,6 +578,13 @@ class Probe:
         out = np.zeros(n, np.float32)
         self._fn("PlaneHit")(_p(pl), _p(org), _p(dirs), _p(tmin), _p(tmax), C.c_int(n), _p(out))
         return out
+
+    def sincos(self, y):
+        """sinf / cosf as generateShadowRay computes them on the device (csrc/rt_glibc_sincosf.h)."""
+        y = _f32(y); n = len(y)
+        s = np.zeros(n, np.float32); c = np.zeros(n, np.float32)
+        self._fn("SinCos")(_p(y), C.c_int(n), _p(s), _p(c))
+        return s, c
 
     def math(self, a, b):
         a = _f32(a); b = _f32(b); n = len(a)

@@ -13,7 +13,16 @@
 
 #include "../../include/rt_types.h"
 
+#define RT_SINCOS_FN __device__ __forceinline__
+#include "rt_glibc_sincosf.h"      // glibc's sinf / cosf / sincosf restated (fp64 polynomial, the FMA build's fusions): the CPU side's bits
+
 namespace rtd {
+
+// sinf / cosf as the CPU oracle's libm computes them (|y| < 120: bit-identical, pinned exhaustively on the host); OCML beyond that range
+__device__ __forceinline__ void rt_sincosf(float y, float& s, float& c) {
+    if (!rt_glibc_sincosf(y, &s, &c)) sincosf(y, &s, &c);
+}
+__device__ __forceinline__ float rt_sinf(float y) { float s, c; rt_sincosf(y, s, c); return s; }
 
 struct f3 { float x, y, z; };
 
@@ -175,7 +184,7 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
     case RT_FLOOR_COAT:    bsdf = B_COAT; ior = 1.5f; albedo = hex_color(0x511845); tint = F3(1, 1, 1); break;
     case RT_FLOOR_DIFFUSE: bsdf = B_DIFFUSE; albedo = hex_color(0x511845); break;
     case RT_FLOOR_CHECKER: {                                                     // checker_layer, material.h:33-36
-        const float sines = sinf(0.2f * hp.x) * sinf(0.2f * hp.y) * sinf(0.2f * hp.z);
+        const float sines = rt_sinf(0.2f * hp.x) * rt_sinf(0.2f * hp.y) * rt_sinf(0.2f * hp.z);
         bsdf = B_DIFFUSE; albedo = (sines < 0) ? hex_color(0x511845) : hex_color(0xff5733);
         break;
     }
@@ -351,8 +360,8 @@ __device__ __forceinline__ float plane_hit(f3 norm, f3 point, const Ray& r, floa
 // Samples the spherical light by solid angle from the path's (already advanced) origin.  Returns false BEFORE any draw when
 // cosAMax is NaN (origin inside the light's sphere, :371-372), false AFTER exactly two draws when the sampled direction is
 // below the surface (:382-383).  `2 * M_PI * x` is a double product narrowed to float at the same two places as the
-// reference (:378, :386); `/ M_PI` divides by (float)M_PI (vec3.h:79).  cosf/sinf: OCML's fp32 sincosf here, glibc on the CPU
-// side - the only place where this function may differ from the oracle (<= 2 ulp in shadowDir; tolerance stated in the tests).
+// reference (:378, :386); `/ M_PI` divides by (float)M_PI (vec3.h:79).  cosf/sinf: glibc's algorithm restated (rt_glibc_sincosf.h) - the
+// bits the CPU oracle's libm produces, so this function is bit-exact against the oracle like everything else.
 struct ShadowSample {
     f3 dir;             // p.shadowDir
     f3 contrib;         // p.lightContribution
@@ -374,7 +383,7 @@ __device__ __forceinline__ bool generate_shadow_ray(f3 lightC, float lightR, f3 
     const float sinA = rt_sqrt(1.0f - cosA * cosA);
     const float phi = (float)(2 * M_PI * (double)eps2);
     float sphi, cphi;
-    sincosf(phi, &sphi, &cphi);
+    rt_sincosf(phi, sphi, cphi);
     const f3 l = sinA * (cphi * su) + sinA * (sphi * sv) + cosA * sw;
     const float dotl = dot(l, normal);
     if (!(dotl > 0)) return false;

@@ -1200,7 +1200,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             // Whole pixels: reserve exactly as many as there are idle lanes, so nothing is hoarded in a wave while
             // other waves idle.  Sample chunks (counter RNG) and the 960 k two-sample items of phase 1 are small and plentiful,
             // one atomic per idle lane-group would serialise on the counter, so a wave reserves 128 at a time into a wave-local pool.
-            const uint32_t cnt = (uint32_t)__popcll(need);
+            // chain waves take ONE pixel per grab (cfg bit 1): all of them start together, so the grabs interleave and the head of the chain lists - the
+            // longest estimates - is dealt one pixel to a wave instead of four neighbours of the list to the first wave that arrives
+            const uint32_t cnt = (role == 0 && (cfg & 2)) ? 1u : (uint32_t)__popcll(need);
             const uint32_t total = s_q[2];
             if (pool_next >= pool_end) {
                 const uint32_t grab = (CHUNKED || PHASE == 1) ? max(cnt, 128u) : cnt;
@@ -1436,26 +1438,19 @@ static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, 
                   : launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 0>(q, blocks, lds, stream, stride, cfg, chain_cfg);
 }
 
-static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream);
+static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
 
-hipError_t RT_LAUNCH_NAME(const RtSphereParams& p_in, int variant, hipStream_t stream) {
-    // the device copy of the parameter block (RtSphereParams::self): one per device, refreshed by every launch.  Only fields that are the same for
-    // every partition of a frame (camera, image size, RNG mode) may be read through it: partitions rendered on ONE device by several streams (the
-    // in-process multi-device path on a single GPU) share the copy.  (Reading the per-pixel fields - framebuffer, parked state, partition - this way
-    // too took the kernel from 61 to 43 spilled SGPRs and gained nothing more: 7030 against 7025 Msamples/s.)
-    static RtSphereParams* dev_copy[16] = { nullptr };
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    if (!dev_copy[dev]) { const hipError_t e = hipMalloc((void**)&dev_copy[dev], sizeof(RtSphereParams)); if (e != hipSuccess) return e; }
-    RtSphereParams p = p_in;
-    p.self = dev_copy[dev];
-    const hipError_t e = hipMemcpyAsync(dev_copy[dev], &p, sizeof p, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return e;
-    return launch_spheres(p, variant, stream);
+hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready) {
+    // p.self: the device copy of the parameter block, owned and refreshed by the renderer (one per device state and frame).  Only fields that are
+    // the same for the whole frame of that device state (camera, image size, RNG mode) are read through it.  (Reading the per-pixel fields -
+    // framebuffer, parked state, partition - this way too took the kernel from 61 to 43 spilled SGPRs and gained nothing more: 7030 against 7025 Msamples/s.)
+    if (!p.self) return hipErrorInvalidValue;
+    return launch_spheres(p, variant, stream, fb_ready);
 }
 
-static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream) {
+static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready) {
+    // every dispatch below that stores pixels into p.fb comes after this wait; the two-dispatch frame waits later (its first dispatch only parks pixel states)
+    auto wait_fb = [&]() -> hipError_t { return fb_ready ? hipStreamWaitEvent(stream, fb_ready, 0) : hipSuccess; };
     int kind = variant & 0xFF;
     const int cb_bits = (variant >> 16) & 0xFF;
     const bool legacy = cb_bits != 0 && cb_bits != 255;
@@ -1484,6 +1479,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
             if (e != hipSuccess) return e;
         }
         const dim3 grid((p.nx + 8 * kWavesPerWg - 1) / (8 * kWavesPerWg), (p.part.local_rows + 7) / 8);
+        { const hipError_t ew = wait_fb(); if (ew != hipSuccess) return ew; }
         if (legacy) hipLaunchKernelGGL(k_render_spheres_tiles<true>, grid, dim3(kThreads), lds, stream, p, coop_below, cull);
         else hipLaunchKernelGGL(k_render_spheres_tiles<false>, grid, dim3(kThreads), lds, stream, p, coop_below, cull);
         return hipGetLastError();
@@ -1517,15 +1513,26 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
     int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24) | (2 << 28);
     int cfg = cull | (boost << 8) | (sparse_max << 16);
-    if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost"
+    static const bool chain_single = getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '1';     // experiments
+    if (chain_single) cfg |= 2;
+    if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost,chain_pixels,chain_pixels_long"
         int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 2;
         sscanf(t, "%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g);
-        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24) | (g << 28);
-        cfg = cull | (e2 << 8) | (sparse_max << 16);
+        // every field is a bit-field of chain_cfg / cfg and some are divisors or loop bounds in the kernel: refuse what does not fit
+        if (a < 1 || a > 255 || b < 0 || b > kWavesPerWg || c < 1 || c > 255 || d < 0 || d > kCostClasses - 1 || e2 < 0 || e2 > 255 ||
+            f < 1 || f > 15 || g < 1 || g > 7) {
+            fprintf(stderr, "rt error: RT_TUNE=%s out of range (chain_every 1..255, chain_waves 0..%d, heavy_thr 1..255, n_chain 0..%d, boost 0..255, "
+                            "chain_pixels 1..15, chain_pixels_long 1..7)\n", t, kWavesPerWg, kCostClasses - 1);
+            return hipErrorInvalidValue;
+        }
+        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24) | (int)((unsigned)g << 28);
+        cfg = cull | (e2 << 8) | (sparse_max << 16) | (chain_single ? 2 : 0);
     }
     const unsigned nb = (unsigned)blocks;
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
     if (p.global_scene) {                       // single dispatch, scattered order
+        e = wait_fb();
+        if (e != hipSuccess) return e;
         e = p.chunks > 1 ? launch_queue_kernel_global<true>(p, nb, stream, stride, cfg, chain_cfg) : launch_queue_kernel_global<false>(p, nb, stream, stride, cfg, chain_cfg);
         if (e != hipSuccess) return e;
         if (p.chunks > 1) {
@@ -1552,6 +1559,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         q.phase = 2;
+        e = wait_fb();
+        if (e != hipSuccess) return e;
         return launch_queue_kernel<2, 2, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
     }
     bool classified = false;
@@ -1568,6 +1577,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         classified = true;
     }
     const bool chunked = p.chunks > 1;
+    e = wait_fb();
+    if (e != hipSuccess) return e;
     if (classified) e = chunked ? launch_queue_kernel<0, 1, true>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 1, false>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
     else e = chunked ? launch_queue_kernel<0, 0, true>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg) : launch_queue_kernel<0, 0, false>(p, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
     if (e != hipSuccess) return e;

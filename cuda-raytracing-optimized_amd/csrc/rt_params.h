@@ -117,7 +117,9 @@ struct RtMeshParams {
 size_t rt_sphere_kernel_lds_bytes(int n_padded, int n);
 
 // Each returns the hipError_t of the launch.  `variant` selects a kernel variant (0 = default).
-hipError_t rt_launch_spheres_parity(const RtSphereParams& p, int variant, hipStream_t stream);
-hipError_t rt_launch_spheres_fast(const RtSphereParams& p, int variant, hipStream_t stream);
+// Sphere launchers: p.self must point to a device copy of `p` that is complete on `stream` before the launch (the renderer owns it);
+// `fb_ready` (may be null): the first dispatch that stores pixels into p.fb waits for this event (the framebuffer poison of the renderer).
+hipError_t rt_launch_spheres_parity(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
+hipError_t rt_launch_spheres_fast(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
 hipError_t rt_launch_mesh_parity(const RtMeshParams& p, int variant, hipStream_t stream);
 hipError_t rt_launch_mesh_fast(const RtMeshParams& p, int variant, hipStream_t stream);

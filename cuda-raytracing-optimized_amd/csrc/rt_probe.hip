@@ -141,6 +141,14 @@ __global__ void k_math(const float* a, const float* b, int n, float* quot, float
     stv(unit3, k, unit(F3(a[k], b[k], a[k] - b[k])));
 }
 
+__global__ void k_sincos(const float* y, int n, float* s_out, float* c_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float s, c;
+    rt_sincosf(y[k], s, c);
+    s_out[k] = s; c_out[k] = c;
+}
+
 __global__ void k_shadow_ray(rt_sphere light, rt_vec3 lightColor, const float* org, const float* atten, const float* normal,
                              const uint32_t* states, int n, float* out9, int* ok, uint32_t* st_after) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,6 +253,13 @@ void PROBE(rtProbeMath)(const float* a_, const float* b_, int n, float* quot, fl
     auto a = in(a_, n); auto b = in(b_, n);
     auto c = outb(quot, n); auto d = outb(root, n); auto e = outb(p5, n); auto f = outb(unit3, (size_t)3 * n);
     hipLaunchKernelGGL(k_math, grid_for(n), dim3(256), 0, 0, a.d, b.d, n, c.d, d.d, e.d, f.d);
+    sync();
+}
+
+void PROBE(rtProbeSinCos)(const float* y_, int n, float* s_out, float* c_out) {
+    auto y = in(y_, n);
+    auto a = outb(s_out, n); auto b = outb(c_out, n);
+    hipLaunchKernelGGL(k_sincos, grid_for(n), dim3(256), 0, 0, y.d, n, a.d, b.d);
     sync();
 }
 

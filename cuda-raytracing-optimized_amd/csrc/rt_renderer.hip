@@ -47,7 +47,10 @@ void hip_check(hipError_t result, const char* func, const char* file, int line) 
 struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipStream_t aux = nullptr;          // second stream: the framebuffer poison runs beside the first dispatch of a frame
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fb_ready = nullptr;
+    RtSphereParams* d_params = nullptr; // device copy of the sphere kernel's parameter block (RtSphereParams::self), one per DeviceState
+    RtSphereParams* h_params = nullptr; // its pinned staging copy (the source of the asynchronous upload must outlive the call)
     // sphere scene
     float4* d_spheres = nullptr;
     float* d_rad = nullptr;
@@ -116,6 +119,16 @@ struct RenderContext {
 
 RenderContext g_ctx;     // kernels.cu:145: one global context per process
 
+// All-ones (a NaN in every float) over `count` chunks of `chunk_words` dwords that lie `pitch_words` apart: the rows of the pinned HOST framebuffer
+// this partition member owns, written over the bus by the device (a host memset of the same rows would cost a millisecond per 11.5 MB frame
+// inside runRenderer; this runs on a second stream beside the frame's first dispatch, which does not touch the framebuffer).
+__global__ void __launch_bounds__(256) k_poison_rows(uint32_t* base, size_t chunk_words, size_t pitch_words, int count) {
+    for (int c = blockIdx.y; c < count; c += gridDim.y) {
+        uint32_t* row = base + (size_t)c * pitch_words;
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunk_words; k += (size_t)gridDim.x * blockDim.x) row[k] = 0xFFFFFFFFu;
+    }
+}
+
 void default_options(rt_render_options* o, int spheres) {
     memset(o, 0, sizeof *o);
     o->sky = spheres ? RT_SKY_GRADIENT : RT_SKY_CONST_GREY;     // kernels.cu:419-424
@@ -144,8 +157,13 @@ void free_device(DeviceState& d) {
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
     fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays);
+    fr(d.d_params);
+    if (d.h_params) HIP_CHECK(hipHostFree(d.h_params));
+    if (d.aux) HIP_CHECK(hipStreamSynchronize(d.aux));
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
     if (d.ev_stop) HIP_CHECK(hipEventDestroy(d.ev_stop));
+    if (d.ev_fb_ready) HIP_CHECK(hipEventDestroy(d.ev_fb_ready));
+    if (d.aux) HIP_CHECK(hipStreamDestroy(d.aux));
     if (d.stream) HIP_CHECK(hipStreamDestroy(d.stream));
     d = DeviceState();
 }
@@ -184,9 +202,13 @@ void setup_devices() {
         if (d.device < 0 || d.device >= count) rt_fail("device index out of range");
         HIP_CHECK(hipSetDevice(d.device));
         HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&d.ev_start));
         HIP_CHECK(hipEventCreate(&d.ev_stop));
+        HIP_CHECK(hipEventCreateWithFlags(&d.ev_fb_ready, hipEventDisableTiming));
         if (c.is_spheres) {
+            HIP_CHECK(hipMalloc((void**)&d.d_params, sizeof(RtSphereParams)));
+            HIP_CHECK(hipHostMalloc((void**)&d.h_params, sizeof(RtSphereParams), hipHostMallocDefault));
             d.d_spheres = upload(c.h_spheres);
             d.d_rad = upload(c.h_rad);
             d.d_mat_color = upload(c.h_mat_color);
@@ -417,7 +439,19 @@ void cleanup_impl() {
 
 extern "C" {
 
-int rtApiVersion(void) { return 1001; }
+int rtApiVersion(void) { return RT_API_VERSION; }
+
+// sizeof of every struct that crosses this C-ABI, in the order of the RT_SIZEOF_* indices (rt_api.h).  A binding (the ctypes mirror, a cgo / JNI stub)
+// compares them with its own view BEFORE the first call that passes one of them: getDefaultRenderOptions and getRenderStats write sizeof(struct)
+// bytes through the caller's pointer, so a mirror that is shorter than the library's struct is a heap overrun, not an error message.
+int rtStructSizes(int32_t* out, int n) {
+    const int32_t sizes[RT_SIZEOF_COUNT] = {
+        (int32_t)sizeof(rt_render_options), (int32_t)sizeof(rt_render_stats), (int32_t)sizeof(rt_camera), (int32_t)sizeof(rt_sphere),
+        (int32_t)sizeof(rt_material), (int32_t)sizeof(rt_triangle), (int32_t)sizeof(rt_bvh_node), (int32_t)sizeof(rt_mesh),
+        (int32_t)sizeof(rt_kernel_scene), (int32_t)sizeof(rt_stexture), (int32_t)sizeof(rt_plane), (int32_t)sizeof(rt_bbox), (int32_t)sizeof(rt_vec3) };
+    for (int k = 0; k < n && k < RT_SIZEOF_COUNT; k++) out[k] = sizes[k];
+    return RT_SIZEOF_COUNT;
+}
 
 int rtDeviceCount(void) {
     int count = 0;
@@ -546,11 +580,41 @@ void runRenderer(int ns, int tx, int ty) {
         part.world = world;
         part.local_rows = (int)d.fb_rows;
         if (c.opt.counters) HIP_CHECK(hipMemsetAsync(d.d_counters, 0, sizeof(RtCounters), d.stream));
-        // Poison the device framebuffer (all-ones = NaN) outside the timed region: every pixel is written exactly once per
-        // frame, so a pixel the work distribution lost shows up as NaN instead of as last frame's (correct-looking) value.
-        if (d.fb_rows > 0) HIP_CHECK(hipMemsetAsync(d.d_fb, 0xFF, d.fb_rows * row_bytes, d.stream));
+        // Finished pixels of the default sphere kernel go straight to the pinned host framebuffer (12 bytes each, spread over the whole frame time):
+        // no device-to-host copy after the kernel.  RT_FB_DIRECT=0 keeps the compact device buffer + copy (every other kernel always does).
+        static const bool fb_direct_env = !(getenv("RT_FB_DIRECT") && getenv("RT_FB_DIRECT")[0] == '0');
+        int spw = ns, chunks = 1;               // sphere path, RT_RNG_COUNTER: samples per work item, work items per pixel
+        if (c.is_spheres && c.opt.rng == RT_RNG_COUNTER && (c.opt.variant & 0xFF) == 0) {
+            const int want = c.opt.samples_per_item > 0 ? c.opt.samples_per_item : 4;
+            if (want < ns) { spw = want; chunks = (ns + want - 1) / want; }
+        }
+        const int vk = c.opt.variant & 0xFF, vcb = (c.opt.variant >> 16) & 0xFF;
+        const bool fb_direct = c.is_spheres && c.max_depth > 0 && fb_direct_env && vk == 0 && (vcb == 0 || vcb == 255) && chunks == 1;
+        rt_vec3* const h_target = c.h_ext ? c.h_ext : c.h_fb;
+        // Poison the framebuffer the kernel WRITES (all-ones = NaN): every pixel is written exactly once per frame, so a pixel the work
+        // distribution lost shows up as NaN instead of as last frame's (correct-looking) value.  The compact device buffer is filled on the
+        // render stream before the timed window; the host framebuffer (direct delivery) is filled by the device on the second stream, and the
+        // launcher makes the first dispatch that stores pixels wait for it (the frame's first dispatch only parks pixel states).
+        hipEvent_t fb_ready = nullptr;
+        if (fb_direct) {
+            void* dp = nullptr;
+            HIP_CHECK(hipHostGetDevicePointer(&dp, (void*)h_target, 0));
+            const size_t stripe_words = (size_t)c.opt.stripe_rows * c.nx * 3;
+            const size_t full = d.fb_rows / (size_t)c.opt.stripe_rows, rem = d.fb_rows % (size_t)c.opt.stripe_rows;
+            uint32_t* base = reinterpret_cast<uint32_t*>(dp) + (size_t)part.rank * stripe_words;
+            if (full > 0)
+                hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)std::min<size_t>((stripe_words + 255) / 256, 64), (unsigned)std::min<size_t>(full, 1024)), dim3(256), 0, d.aux,
+                                   base, stripe_words, (size_t)world * stripe_words, (int)full);
+            if (rem > 0)
+                hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)std::min<size_t>((rem * c.nx * 3 + 255) / 256, 64), 1), dim3(256), 0, d.aux,
+                                   base + full * (size_t)world * stripe_words, rem * (size_t)c.nx * 3, (size_t)0, 1);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(d.ev_fb_ready, d.aux));
+            fb_ready = d.ev_fb_ready;
+        } else if (d.fb_rows > 0) {
+            HIP_CHECK(hipMemsetAsync(d.d_fb, 0xFF, d.fb_rows * row_bytes, d.stream));
+        }
         HIP_CHECK(hipEventRecord(d.ev_start, d.stream));
-        bool fb_direct = false;
         if (c.max_depth <= 0) {
             HIP_CHECK(hipMemsetAsync(d.d_fb, 0, d.fb_rows * row_bytes, d.stream));     // loop of kernels.cu:402 never runs
         } else if (c.is_spheres) {
@@ -569,20 +633,16 @@ void runRenderer(int ns, int tx, int ty) {
             p.order = d.d_order;
             // work items: one per pixel in the reference-stream mode (a pixel's samples are one sequential RNG stream);
             // with the per-sample counter stream the samples are independent and a pixel is split into chunks
-            p.spw = ns; p.chunks = 1; p.partial = nullptr;
+            p.spw = spw; p.chunks = chunks; p.partial = nullptr;
             p.phase = 0; p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays;
-            if (c.opt.rng == RT_RNG_COUNTER && (c.opt.variant & 0xFF) == 0) {
-                const int spw = c.opt.samples_per_item > 0 ? c.opt.samples_per_item : 4;
-                if (spw < ns) {
-                    p.spw = spw; p.chunks = (ns + spw - 1) / spw;
-                    const size_t need = d.fb_rows * c.nx * (size_t)p.chunks * sizeof(rt_vec3);
-                    if (need > d.partial_bytes) {
-                        if (d.d_partial) HIP_CHECK(hipFree(d.d_partial));
-                        HIP_CHECK(hipMalloc((void**)&d.d_partial, need));
-                        d.partial_bytes = need;
-                    }
-                    p.partial = d.d_partial;
+            if (chunks > 1) {
+                const size_t need = d.fb_rows * c.nx * (size_t)p.chunks * sizeof(rt_vec3);
+                if (need > d.partial_bytes) {
+                    if (d.d_partial) HIP_CHECK(hipFree(d.d_partial));
+                    HIP_CHECK(hipMalloc((void**)&d.d_partial, need));
+                    d.partial_bytes = need;
                 }
+                p.partial = d.d_partial;
             }
             static const char* dbg_path = getenv("RT_WAVE_DEBUG");      // diagnostics: per-wave time stamps -> file
             const size_t dbg_bytes = (size_t)65536 * 8 * sizeof(unsigned long long);
@@ -593,19 +653,19 @@ void runRenderer(int ns, int tx, int ty) {
             }
             if (c.opt.nee) rt_fail("runRenderer: next-event estimation is only defined for mesh scenes");
             if (c.opt.floor) rt_fail("runRenderer: the floor plane is only defined for mesh scenes (kernel_scene.floor)");
-            // Finished pixels go straight to the pinned host framebuffer (12 bytes each, spread over the whole frame time) when the default kernel
-            // writes them itself: no device-to-host copy after the kernel.  RT_FB_DIRECT=0 keeps the compact device buffer + copy.
-            static const bool fb_direct_env = !(getenv("RT_FB_DIRECT") && getenv("RT_FB_DIRECT")[0] == '0');
-            const int vk = c.opt.variant & 0xFF, vcb = (c.opt.variant >> 16) & 0xFF;
-            fb_direct = fb_direct_env && vk == 0 && (vcb == 0 || vcb == 255) && p.chunks == 1;
             if (fb_direct) {
                 void* dp = nullptr;
-                HIP_CHECK(hipHostGetDevicePointer(&dp, c.h_ext ? (void*)c.h_ext : (void*)c.h_fb, 0));
+                HIP_CHECK(hipHostGetDevicePointer(&dp, (void*)h_target, 0));
                 p.fb = reinterpret_cast<rt_vec3*>(dp);
                 p.fb_global_rows = 1;
             }
-            HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream)
-                                             : rt_launch_spheres_parity(p, c.opt.variant, d.stream));
+            // the device copy of the parameter block (RtSphereParams::self): owned by this DeviceState, refreshed by every frame from a pinned
+            // staging copy (runRenderer is synchronous: the previous frame's upload has completed)
+            p.self = d.d_params;
+            *d.h_params = p;
+            HIP_CHECK(hipMemcpyAsync(d.d_params, d.h_params, sizeof(RtSphereParams), hipMemcpyHostToDevice, d.stream));
+            HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream, fb_ready)
+                                             : rt_launch_spheres_parity(p, c.opt.variant, d.stream, fb_ready));
             launches++;
         } else {
             RtMeshParams p;

@@ -64,8 +64,18 @@ void getRenderStats(rt_render_stats* out);
 /* Number of HIP devices visible to the process (0 if none). Never exits. */
 int rtDeviceCount(void);
 
-/* Library/ABI version: major*1000 + minor. */
+/* Library/ABI version: major*1000 + minor.  Bumped whenever rt_render_options or rt_render_stats (or any other struct of rt_types.h)
+ * changes size or layout; a binding refuses a library whose version differs from the RT_API_VERSION it was written against. */
+#define RT_API_VERSION 1002
 int rtApiVersion(void);
+
+/* sizeof of every struct that crosses this boundary, as the LIBRARY was compiled: out[RT_SIZEOF_*], at most n entries written; returns
+ * RT_SIZEOF_COUNT.  getDefaultRenderOptions / getRenderStats write sizeof(struct) bytes through the caller's pointer, so a binding checks
+ * these against its own mirror before the first such call (the Python mirror does so in load_renderer(): a mismatch is an ImportError). */
+enum { RT_SIZEOF_RENDER_OPTIONS = 0, RT_SIZEOF_RENDER_STATS, RT_SIZEOF_CAMERA, RT_SIZEOF_SPHERE, RT_SIZEOF_MATERIAL, RT_SIZEOF_TRIANGLE,
+       RT_SIZEOF_BVH_NODE, RT_SIZEOF_MESH, RT_SIZEOF_KERNEL_SCENE, RT_SIZEOF_STEXTURE, RT_SIZEOF_PLANE, RT_SIZEOF_BBOX, RT_SIZEOF_VEC3,
+       RT_SIZEOF_COUNT };
+int rtStructSizes(int32_t* out, int n);
 
 #ifdef __cplusplus
 }

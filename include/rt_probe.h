@@ -20,6 +20,7 @@
  *   rtProbeShadowRay    generateShadowRay as a whole          kernels.cu:363-393 (out9 = shadowDir, lightContribution, lightDist,
  *                                                             cosAMax, number of draws consumed; generated = its bool result)
  *   rtProbePlaneHit     planeHit                              intersections.h:43-52
+ *   rtProbeSinCos       sinf / cosf of generateShadowRay      kernels.cu:378-379 (glibc's algorithm restated: csrc/rt_glibc_sincosf.h)
  */
 #ifndef RT_PROBE_H
 #define RT_PROBE_H
@@ -48,7 +49,8 @@ void rtProbeScatter##sfx(const float* t, const float* p3, const float* normal3, 
 void rtProbeMath##sfx(const float* a, const float* b, int n, float* quot, float* root, float* p5, float* unit3); \
 void rtProbeShadowRay##sfx(const rt_sphere* light, const rt_vec3* lightColor, const float* org3, const float* atten3, const float* normal3, \
                            const uint32_t* states, int n, float* out9, int* generated, uint32_t* st_after); \
-void rtProbePlaneHit##sfx(const rt_plane* planes, const float* org3, const float* dir3, const float* tmin, const float* tmax, int n, float* t_out);
+void rtProbePlaneHit##sfx(const rt_plane* planes, const float* org3, const float* dir3, const float* tmin, const float* tmax, int n, float* t_out); \
+void rtProbeSinCos##sfx(const float* y, int n, float* sin_out, float* cos_out);
 
 RT_PROBE_DECL(_parity)
 RT_PROBE_DECL(_fast)

@@ -74,11 +74,28 @@ _oracle = None
 _ref = None
 
 
+def _check_abi(lib, fn, path):
+    """Refuses a library whose structs differ in size from the ctypes mirrors above (a rebuilt .so beside a stale mirror, or the reverse,
+    would otherwise overrun the caller's buffer inside orc_render / ref_render_*)."""
+    rt = _pkg()
+    if not hasattr(lib, fn):
+        raise ImportError(f"{path} predates the ABI handshake ({fn} missing): rebuild it (make -C oracle)")
+    out = (C.c_int32 * 4)()
+    getattr(lib, fn).argtypes = [C.POINTER(C.c_int32), C.c_int]
+    getattr(lib, fn).restype = C.c_int
+    n = getattr(lib, fn)(out, 4)
+    mine = [C.sizeof(orc_scene), C.sizeof(orc_counters), C.sizeof(orc_scatter), C.sizeof(rt.render_options)]
+    if n != 4 or list(out) != mine:
+        raise ImportError(f"{path}: struct sizes {list(out)} (orc_scene, orc_counters, orc_scatter, rt_render_options) differ from the Python "
+                          f"mirror's {mine}: library and oracle/oracle.py are of different generations - rebuild (make -C oracle)")
+
+
 def load_oracle():
     global _oracle
     if _oracle is None:
         rt = _pkg()
         lib = C.CDLL(ORACLE_LIB)
+        _check_abi(lib, "orc_abi_sizes", ORACLE_LIB)
         _bind_common(lib, "orc_")
         lib.orc_render.argtypes = [C.POINTER(orc_scene), C.POINTER(rt.camera), C.POINTER(rt.render_options),
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -105,6 +122,7 @@ def load_ref():
     if _ref is None:
         rt = _pkg()
         lib = C.CDLL(REF_LIB)
+        _check_abi(lib, "ref_abi_sizes", REF_LIB)
         _bind_common(lib, "ref_")
         lib.ref_struct_sizes.argtypes = [C.POINTER(C.c_int), C.c_int]; lib.ref_struct_sizes.restype = C.c_int
         lib.ref_probe_light_dir.argtypes = [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp]

@@ -83,6 +83,13 @@ int ref_struct_sizes(int* out, int cap) {
     return n;
 }
 
+/* the same handshake as orc_abi_sizes (rt_oracle.h): the structs of OURS that the shim's entry points read or write through caller pointers */
+int ref_abi_sizes(int32_t* out, int n) {
+    const int32_t s[4] = { (int32_t)sizeof(orc_scene), (int32_t)sizeof(orc_counters), (int32_t)sizeof(orc_scatter), (int32_t)sizeof(rt_render_options) };
+    for (int k = 0; k < n && k < 4; k++) out[k] = s[k];
+    return 4;
+}
+
 uint32_t ref_wang_hash(uint32_t seed) { return wang_hash(seed); }
 uint32_t ref_pixel_seed(uint32_t pixel_id) { return (wang_hash(pixel_id) * 336343633) | 1; }
 uint32_t ref_xor_shift_32(uint32_t* state) { return xor_shift_32(*state); }

@@ -765,3 +765,43 @@ double orc_rmse(const rt_vec3* f, const rt_vec3* g, int n) {    /* main.cpp:117-
             error += (f[i].e[c] - g[i].e[c]) * (f[i].e[c] - g[i].e[c]) / 3.0;
     return sqrt(error / n);
 }
+
+/* sizeof of every struct the Python binding mirrors (oracle/oracle.py checks them at load time: orc_render writes sizeof(orc_counters)
+ * bytes through the caller's pointer, so a stale mirror would be a heap overrun, not an error message). */
+int orc_abi_sizes(int32_t* out, int n) {
+    const int32_t s[4] = { (int32_t)sizeof(orc_scene), (int32_t)sizeof(orc_counters), (int32_t)sizeof(orc_scatter), (int32_t)sizeof(rt_render_options) };
+    for (int k = 0; k < n && k < 4; k++) out[k] = s[k];
+    return 4;
+}
+
+/* ---- the device's sine / cosine, checked against THIS machine's libm -----------------------------------------------------------------
+ * cuda-raytracing-optimized_amd/csrc/rt_glibc_sincosf.h restates glibc's sinf / cosf / sincosf (the functions generate_shadow_ray above calls)
+ * for the device; the same text is compiled here for the host and compared with libm.  Test infrastructure (tests/test_oracle_golden.py). */
+#define RT_SINCOS_FN static inline
+#include "../cuda-raytracing-optimized_amd/csrc/rt_glibc_sincosf.h"
+
+int orc_glibc_sincosf_twin(float y, float* s, float* c) { return rt_glibc_sincosf(y, s, c); }
+
+/* mode 0: the 2^24 arguments of generateShadowRay, phi_k = (float)(2 * M_PI * (k / 16777216.0f)) for k in [k0, k1);
+ * mode 1: arguments k * step for k in [k0, k1) (signed sweep).  Returns the number of arguments on which the twin differs in any bit from libm's
+ * sinf, cosf or sincosf; *first_bad receives the first such argument. */
+long orc_glibc_sincosf_twin_mismatches(int mode, long k0, long k1, float step, float* first_bad) {
+    long bad = 0;
+    for (long k = k0; k < k1; k++) {
+        const float y = mode == 0 ? (float)(2 * M_PI * (double)((float)k / 16777216.0f)) : (float)k * step;
+        float ts, tc, ls, lc;
+        if (!rt_glibc_sincosf(y, &ts, &tc)) continue;
+        const float s1 = sinf(y), c1 = cosf(y);
+        sincosf(y, &ls, &lc);
+        if (memcmp(&ts, &s1, 4) || memcmp(&tc, &c1, 4) || memcmp(&ts, &ls, 4) || memcmp(&tc, &lc, 4)) {
+            if (bad == 0 && first_bad) *first_bad = y;
+            bad++;
+        }
+    }
+    return bad;
+}
+
+/* libm's sincosf over an array (the expected values of the device probe rtProbeSinCos) */
+void orc_libm_sincosf(const float* y, int n, float* s, float* c) {
+    for (int k = 0; k < n; k++) { s[k] = sinf(y[k]); c[k] = cosf(y[k]); }
+}

@@ -116,6 +116,9 @@ uint32_t orc_linear_to_srgb(float x);
 /* main.cpp:117-125 */
 double orc_rmse(const rt_vec3* f, const rt_vec3* g, int n);
 
+/* {sizeof orc_scene, orc_counters, orc_scatter, rt_render_options} as this library was compiled; returns 4 (binding handshake) */
+int orc_abi_sizes(int32_t* out, int n);
+
 #ifdef __cplusplus
 }
 #endif

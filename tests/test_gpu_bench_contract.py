@@ -28,14 +28,15 @@ def test_bench_prints_the_contract_line():
     rf = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] < 1.0
-    assert rf["effective_frac"] == rf["frac"] and 0.0 < rf["executed"]["frac"] < rf["frac"]      # culling: executed work < algorithmic work
-    assert 5.0 < rf["executed"]["exec_tests_per_ray"] < 488.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.0 < rf["frac"] <= 1.0       # executed flops: a fraction of the peak by construction
+    assert rf["effective_frac"] > rf["frac"]                                                      # culling: executed work < the brute-force scan's work
+    assert 5.0 < rf["executed_per_ray"]["sphere_tests"] < 488.0
     # every other BASELINE.json config rides in the same line
     oc = d["other_configs"]
     assert set(oc) == {"C3", "C4", "C5_one_gpu"}
     for k in oc:
         assert oc[k]["unit"] == "Msamples/s" and oc[k]["value"] > 100.0 and "workload" in oc[k] and "roofline" in oc[k], k
+        assert 0.0 < oc[k]["roofline"]["frac"] <= 1.0, (k, oc[k]["roofline"]["frac"])              # every roofline of the line is a roofline
     assert "1000spp" in oc["C3"]["workload"] and "1920x1080 256spp" in oc["C4"]["workload"] and "3840x2160 4096spp" in oc["C5_one_gpu"]["workload"]
     r4 = oc["C4"]["roofline"]
     assert r4["bound"] == "l2-gather" and r4["unit"] == "TB/s" and abs(r4["frac"] - r4["achieved"] / r4["peak"]) < 1e-9 and 0.0 < r4["frac"] < 1.0

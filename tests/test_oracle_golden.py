@@ -176,3 +176,21 @@ def test_dormant_presets(rt, O, lib):
     # the subsurface preset did scatter inside the medium somewhere (t shortened, direction not normalised)
     sss = g["kind"] == rt.RT_MODEL_SSS
     assert (g["t_out"][sss] < g["t"][sss]).any()
+
+
+def test_glibc_sincosf_twin_is_libm(O):
+    """cuda-raytracing-optimized_amd/csrc/rt_glibc_sincosf.h - the sine / cosine the DEVICE computes in generateShadowRay - compiled for the host
+    (oracle/rt_oracle.c includes the same text) equals this machine's libm sinf, cosf AND sincosf in every bit on all 2^24 arguments
+    phi = (float)(2 pi k 2^-24) the light sampling can produce (kernels.cu:375-379), and on 2^22 arguments spread over (-120, 120)."""
+    import ctypes as C
+    lib = O.load_oracle()
+    f = lib.orc_glibc_sincosf_twin_mismatches
+    f.argtypes = [C.c_int, C.c_long, C.c_long, C.c_float, C.POINTER(C.c_float)]
+    f.restype = C.c_long
+    bad = C.c_float(0)
+    assert f(0, 0, 1 << 24, 0.0, C.byref(bad)) == 0, bad.value
+    assert f(1, -(1 << 21), 1 << 21, 119.9 / (1 << 21), C.byref(bad)) == 0, bad.value
+    s, c = C.c_float(), C.c_float()
+    lib.orc_glibc_sincosf_twin.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    assert lib.orc_glibc_sincosf_twin(121.0, C.byref(s), C.byref(c)) == 0          # beyond the restated range: the caller falls back
+    assert lib.orc_glibc_sincosf_twin(float("inf"), C.byref(s), C.byref(c)) == 0

@@ -55,6 +55,46 @@ for W, per_frame in (("C2", 2), ("C4", 1)):
         cyc = g("GRBM_GUI_ACTIVE") / 8.0
         lines.append("kernel cycles per frame (GRBM_GUI_ACTIVE / 8 XCDs) %.4g ; VALU wave-instructions per SIMD-cycle = %.3f (1024 SIMDs; 0.5 = the 2-cycle issue limit)" %
                      (cyc, g("SQ_INSTS_VALU") / (1024.0 * cyc)))
+    pmc = {}
+    if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE") and g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        cyc = g("GRBM_GUI_ACTIVE") / 8.0
+        issue = g("SQ_INSTS_VALU") / (1024.0 * cyc)
+        lane = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+        pmc = {"valu_insts_per_simd_cycle": issue, "valu_issue_frac": issue / 0.5, "valu_lane_utilisation": lane,
+               "useful_lane_issue_frac": issue / 0.5 * lane,
+               "definition": "SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) against the 0.5 per cycle issue limit (one wave64 VALU instruction per 2 "
+                             "cycles per SIMD); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); their product = the share of the "
+                             "chip's lane-issue slots that did useful work"}
+        if g("SQ_WAVE_CYCLES"):
+            for k, nm in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any")):
+                if g(k):
+                    pmc[nm] = g(k) / g("SQ_WAVE_CYCLES")
+        if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None:
+            pmc["lds_bank_conflict_ratio"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+            lines.append("SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = %.3f" % pmc["lds_bank_conflict_ratio"])
+        lines.append("useful lane-issue fraction = (VALU insts per SIMD-cycle / 0.5) x lane utilisation = %.3f x %.3f = %.3f" % (issue / 0.5, lane, issue / 0.5 * lane))
+    plain = os.path.join(d, "plain.log")
+    if os.path.exists(plain):
+        for ln in open(plain):
+            if ln.startswith("{"):
+                pj = json.loads(ln)
+                lines.append("== un-profiled run of the same program: kernel ms per frame %s ==" % [round(x, 3) for x in pj["kernel_ms"]])
+                dc = pj.get("device_counters")
+                if dc:
+                    lines.append("device counters of one frame (the inputs of bench.py's roofline.frac): %s" % json.dumps(dc))
+                    if W != "C4":
+                        ex = 18.0 * dc["exec_tests"] + 20.0 * dc["box_tests"] + 80.0 * dc["rays"]
+                        ms = min(pj["kernel_ms"])
+                        lines.append("executed flops = 18 x exec_tests + 20 x box_tests + 80 x rays = %.4g ; / %.3f ms = %.2f TFLOP/s = %.3f of 157.3 (roofline.frac)" %
+                                     (ex, ms, ex / ms / 1e9, ex / ms / 1e9 / 157.3))
+                        eff = dc["rays"] * (18.0 * 488 + 80.0)
+                        lines.append("brute-force-equivalent flops = rays x (18 x 488 + 80) = %.4g ; -> %.2f TFLOP/s = %.3f of 157.3 (roofline.effective_frac)" %
+                                     (eff, eff / ms / 1e9, eff / ms / 1e9 / 157.3))
+                    else:
+                        by = 48.0 * dc["node_visits"] + 64.0 * dc["prim_tests"] + 64.0 * dc["rays"]
+                        ms = min(pj["kernel_ms"])
+                        lines.append("algorithmic gather bytes = 48 x node_visits + 64 x prim_tests + 64 x rays = %.4g ; / %.3f ms = %.2f TB/s = %.3f of 18.8 (roofline.frac)" %
+                                     (by, ms, by / ms / 1e9, by / ms / 1e9 / 18.8))
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         by = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
         w = bench.WORKLOADS[W]
@@ -64,7 +104,7 @@ for W, per_frame in (("C2", 2), ("C4", 1)):
         if W == "C4":
             lines.append("(C4: the reads are node records and triangle slots - 6.7 MB touched, one XCD's L2 holds 4 MB, the Infinity Cache the rest; the kernel's "
                          "algorithmic GATHER bytes, which its roofline counts, are ~4 TB per frame: bench.py other_configs.C4.roofline)")
-        out[W] = {"bytes_per_frame": by, "fetch_kb_x2": 2 * g("FETCH_SIZE"), "write_kb": g("WRITE_SIZE"), "frame_ms": (sum(frames) / len(frames)) if frames else None,
+        out[W] = {"pmc": pmc, "bytes_per_frame": by, "fetch_kb_x2": 2 * g("FETCH_SIZE"), "write_kb": g("WRITE_SIZE"), "frame_ms": (sum(frames) / len(frames)) if frames else None,
                   "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes around tools/one_frame.py, FETCH x2 (gfx950), last full frame"}
     open(os.path.join(ROOT, "gpurun_out", f"{tag}_{W}_summary.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

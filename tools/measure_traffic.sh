@@ -13,6 +13,7 @@ for W in C2 C4; do
   OUT=$REPO/gpurun_out/prof_${TAG}_$W
   rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 tools/one_frame.py $W 3 > $OUT/trace.log 2>&1
+  RT_ONE_FRAME_COUNTERS=1 python3 tools/one_frame.py $W 3 > $OUT/plain.log 2>&1        # un-profiled frame times + the device counters of the frame
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -o pmc1 -- python3 tools/one_frame.py $W 2 > $OUT/pmc1.log 2>&1
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc2 -o pmc2 -- python3 tools/one_frame.py $W 2 > $OUT/pmc2.log 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $OUT/pmc3 -o pmc3 -- python3 tools/one_frame.py $W 2 > $OUT/pmc3.log 2>&1

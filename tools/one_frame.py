@@ -14,5 +14,8 @@ b = bench.HipBackend()
 b.open(w, 0, 1, None)
 b.step(1)
 ms = [b.step() for _ in range(frames)]
+out = {"workload": name, "frames": frames, "kernel_ms": ms, "Msamples_per_s": w["nx"] * w["ny"] * w["spp"] / min(ms) / 1e3}
+if os.environ.get("RT_ONE_FRAME_COUNTERS"):          # the inputs of bench.py's roofline.frac: device counters of the same frame (an extra, untimed frame)
+    out["device_counters"] = b.counted(w["spp"])
 b.close()
-print(json.dumps({"workload": name, "frames": frames, "kernel_ms": ms, "Msamples_per_s": w["nx"] * w["ny"] * w["spp"] / min(ms) / 1e3}))
+print(json.dumps(out))
