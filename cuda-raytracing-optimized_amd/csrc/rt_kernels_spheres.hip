@@ -731,6 +731,56 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     return out;
 }
 
+// ---- closest hit, SINGLE-RAY form: the wave has exactly one live ray ------------------------------------------------------
+// The frame cannot end before its longest pixel has traced its rays one after the other (one RNG stream per pixel, kernels.cu:541-548; the
+// longest pixels of the benchmark frame sit in the wedge where a sphere rests on the ground: ~3700 rays of 50 diffuse bounces each sample,
+// three draws per bounce - nothing to overlap), so for such a pixel the LATENCY of one ray step is the whole cost.  The sparse form above
+// walks three dependent phases through LDS lists (big spheres -> group boxes -> reachable spheres); with a single ray the shortest dependency
+// chain is the brute-force one: the ray is broadcast through SGPRs, every lane runs the fused pre-test on slots lane, lane + 64, ... (8 rounds of
+// independent LDS reads for the 488-sphere scene), resolves its own candidates with the literal sphereHit tail, and the per-lane (t, original
+// index) keys are merged on the scalar unit.  Same pre-test and slack as sparse_test_slot, same exact tail, same tie rule.  WAVE-LEVEL; q is
+// wave-uniform; at most 32 rounds (2048 slots).
+__device__ __forceinline__ Hit scan_single(const RtSphereParams& P, const SceneLds& S, int q, f3 org, f3 dn, float a) {
+    const int lane = threadIdx.x & 63;
+    auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q)); };
+    const f3 O = F3(bc(org.x), bc(org.y), bc(org.z)), D = F3(bc(dn.x), bc(dn.y), bc(dn.z));
+    const float A = bc(a);
+    const float Ak = A - 3.814697265625e-6f;
+    const int rounds = P.n_padded >> 6;
+    uint32_t mask = 0;
+#pragma unroll 4
+    for (int r = 0; r < rounds; r++) {
+        const float4 sph = S.sph[sidx((r << 6) + lane)];
+        const f3 oc = O - F3(sph.x, sph.y, sph.z);
+        const float b = __builtin_fmaf(oc.z, D.z, __builtin_fmaf(oc.y, D.y, oc.x * D.x));
+        const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -sph.w)));
+        const float v = __builtin_fmaf(Ak, c, -__builtin_fmaf(b, b, 7.62939453125e-6f * sph.w));
+        mask |= (__float_as_uint(v) >> 31) << r;                     // flagged: see sparse_test_slot
+    }
+    Hit h = { FLT_MAX, -1, 0x7fffffff };
+    while (mask) {
+        const int r = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const int k = (r << 6) + lane;
+        const float t = sphere_hit_exact(S.sph[sidx(k)], O, D, A, P.t_min, FLT_MAX);
+        const int o = S.orig[k];
+        if (o != 0x7fffffff && t < FLT_MAX) accept(h, t, k, o);
+    }
+    // merge: lexicographic minimum of (t, orig) over the lanes that found something (t > t_min >= 0: the bit patterns order like the values)
+    unsigned long long found = __ballot(h.closest < FLT_MAX);
+    uint32_t st = __float_as_uint(FLT_MAX);
+    int sk = -1, so = 0x7fffffff;
+    while (found) {
+        const int bq = __builtin_ctzll(found);
+        found &= found - 1;
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(h.closest), bq);
+        const int ob = __builtin_amdgcn_readlane(h.orig, bq);
+        if (tb < st || (tb == st && ob < so)) { st = tb; so = ob; sk = __builtin_amdgcn_readlane(h.sid, bq); }
+    }
+    Hit out = { __uint_as_float(st), sk, so };
+    return out;
+}
+
 // ---- shading of one hit / miss: the rest of color()'s loop body (kernels.cu:415-531) -------------------------------
 // Returns true when the path ended (the caller accumulates L.pcolor and starts the next sample).
 __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S, Lane& L, f3 dn, Hit h) {
@@ -771,7 +821,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr) {
+                                           uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
@@ -783,6 +833,11 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
     lap(0);
     if (!LEGACY) {                                                   // default: pair-compacted scan, sparse form for the tail
         // (the sparse form lists its reachable (ray, group) pairs in the wave's pair list: rays x groups must fit it)
+        if (single && __popcll(live) == 1 && P.n_padded <= 2048 && sparse_max > 0) {     // one live ray: the shortest dependency chain (scan_single)
+            const Hit hq = scan_single(P, S, (int)__builtin_ctzll(live), L.org, dn, a);
+            if (has_ray) h = hq;
+            if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[6] += n_ - tc; tc = n_; }
+        } else
         if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && P.n_groups <= 4096 &&
             (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap) { h = scan_sparse(P, S, L.org, dn, a, live, cull, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
         else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
@@ -936,9 +991,11 @@ __global__ void __launch_bounds__(kThreads) k_classify_spheres(const RtSpherePar
 // class 0: >= 6 rays per sample (candidates for the very long chains); class kCostClasses-1: one ray per sample in the
 // whole window (sky).  Two passes (PASS 0 counts, PASS 1 fills) make the lists compact: P.order holds each pixel once.
 // P.queue[4 + c] = length of list c;  P.queue[4 + kCostClasses + c] = fill cursor of list c.
-constexpr int kCostClasses = 17;
-constexpr int kChainClasses = 3;      // lists 0..2: >= 12 rays per sample, the chains -> chain waves (see k_render_spheres_queue)
-constexpr int kHeavyClasses = 3;      // lists 3..5: 6..12 rays per sample -> spread over the first fill of the normal waves
+constexpr int kCostClasses = 18;
+constexpr int kChainClasses = 4;      // lists 0..3: >= 12 rays per sample, the chains -> chain waves (see k_render_spheres_queue); list 0 (>= P.chain_top_thr / 16
+                                      // rays per sample: ~100 of the 960 k pixels of the benchmark frame, among them the 45 that need > 3000 rays) has waves
+                                      // that hold ONE pixel (kernel parameter `caps`) and trace it in the single-ray form (scan_single)
+constexpr int kHeavyClasses = 3;      // lists 4..6: 6..12 rays per sample -> spread over the first fill of the normal waves
 
 __device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr) {
     uint32_t sum = 0, cnt = 0;
@@ -956,7 +1013,7 @@ __device__ __forceinline__ int cost_class(const RtSphereParams& P, int i, int lr
     // the window mean under-rates an isolated long pixel (its neighbours miss the glass): never below 3/4 of the pixel's own rate
     const uint32_t own = (P.px_rays[(size_t)lr * P.nx + i] * 12u) / (uint32_t)P.s_split;
     const uint32_t e = max((sum * 16u) / (cnt * (uint32_t)P.s_split), own);
-    const uint32_t lim[kCostClasses - 1] = { 320u, 240u, 192u, 160u, 128u, 96u, 72u, 56u, 44u, 36u, 30u, 26u, 22u, 19u, 18u, 17u };
+    const uint32_t lim[kCostClasses - 1] = { (uint32_t)P.chain_top_thr, 320u, 240u, 192u, 160u, 128u, 96u, 72u, 56u, 44u, 36u, 30u, 26u, 22u, 19u, 18u, 17u };
     int cls = kCostClasses - 1;
 #pragma unroll
     for (int c = kCostClasses - 2; c >= 0; c--) if (e >= lim[c]) cls = c;
@@ -1054,7 +1111,7 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // chain wave holds while one of them comes from list 0 (the longest chains).
 //   SCENE    where the scene is read from (stage_scene): 0 = an LDS copy, 1 = global memory, 2 = test data in the LDS, hit data in global memory
 template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0>
-__global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg) {
+__global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
     const SceneLds S = stage_scene<false, SCENE>(P, smem, &unused);
@@ -1106,8 +1163,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     // (Tried and dropped: half-occupied "medium" waves for the heavy lists - what they gain in the tail they lose in throughput.)
     int role = 2;
     if (CLS == 2 && s_q[0] > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
-    bool tier0 = false;                 // the lane's pixel came from a chain list (fetched while the wave had role 0)
-    bool long0 = false;                 // ... from list 0, the longest chains: such a wave holds fewer pixels (a sparse step costs ~2 us + 0.8 us per live ray)
+    int ccls = 7;                       // chain list (0 .. kChainClasses - 1) the lane's pixel came from (fetched while the wave had role 0), 7 = none.  A wave that
+                                        // holds a pixel of list c holds at most caps[c] pixels (4 bits each)
 
     Lane L;
     L.col = F3(0, 0, 0);
@@ -1189,8 +1246,12 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
             int cap = 64;
-            if (CLS == 2 && (role == 0 || __ballot(have_pixel && tier0) != 0ull))
-                cap = (__ballot(have_pixel && long0) != 0ull) ? ((chain_cfg >> 28) & 0xF) : ((chain_cfg >> 12) & 0xF);
+            if (CLS == 2 && (role == 0 || __ballot(have_pixel && ccls < 7) != 0ull)) {
+                cap = (chain_cfg >> 12) & 0xF;
+                if (__ballot(have_pixel && ccls == 2) != 0ull) cap = min(cap, (caps >> 8) & 0xF);
+                if (__ballot(have_pixel && ccls == 1) != 0ull) cap = min(cap, (caps >> 4) & 0xF);
+                if (__ballot(have_pixel && ccls == 0) != 0ull) cap = min(cap, caps & 0xF);
+            }
             const int allowed = cap - (int)__popcll(live_m);
             if (allowed <= 0) break;
             const unsigned long long idle_m = ~live_m;
@@ -1205,7 +1266,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             const uint32_t cnt = (role == 0 && (cfg & 2)) ? 1u : (uint32_t)__popcll(need);
             const uint32_t total = s_q[2];
             if (pool_next >= pool_end) {
-                const uint32_t grab = (CHUNKED || PHASE == 1) ? max(cnt, 128u) : cnt;
+                // (PHASE 2, experiments: cfg bits 3..7 x 4 = positions a normal wave reserves at least per grab)
+                const uint32_t grab = (CHUNKED || PHASE == 1) ? max(cnt, 128u) : ((PHASE == 2 && role == 2) ? max(cnt, (uint32_t)((cfg >> 3) & 0x1F) * 4u) : cnt);
                 const uint32_t limit = role == 0 ? s_q[0] : total;
                 uint32_t b = 0;
                 if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : 0), grab);
@@ -1298,8 +1360,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     }
                     need_sample = true;
                     have_pixel = true;
-                    tier0 = role == 0;
-                    long0 = CLS == 2 && role == 0 && pos < s_cls_pos[1];
+                    ccls = 7;
+                    if (CLS == 2 && role == 0) { ccls = 0; for (int k = 1; k < kChainClasses; k++) if (pos >= s_cls_pos[k]) ccls = k; }
                 }
             }
         }
@@ -1338,7 +1400,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             }
             if (sel) { nrays++; pix_rays++; }
             if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            const bool done = trace_rays<false>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr);
+            const bool done = trace_rays<false>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr, (cfg & 4) != 0);
             if (DBG && wdbg) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel, steps > 1);
         }
@@ -1413,12 +1475,12 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {                       /
 template <bool CHUNKED>
 static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned blocks, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
     const size_t lds = (size_t)kWavesPerWg * kWaveScratch;          // only the per-wave scratch: the scene stays in global memory
-    hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, 1>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, 1>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, 0x4444);
     return hipGetLastError();
 }
 
 template <int PHASE, int CLS, bool CHUNKED, int SCENE>
-static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
+static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg, int caps) {
     // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
     const void* kern = q.wave_dbg ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>)
                                   : reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
@@ -1426,16 +1488,16 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
-    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg);
+    if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
+    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
     return hipGetLastError();
 }
 
 // `hybrid`: stage_scene's form 2 (test data in the LDS, hit data in global memory)
 template <int PHASE, int CLS, bool CHUNKED>
-static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, size_t lds, bool hybrid, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
-    return hybrid ? launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 2>(q, blocks, lds, stream, stride, cfg, chain_cfg)
-                  : launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 0>(q, blocks, lds, stream, stride, cfg, chain_cfg);
+static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, size_t lds, bool hybrid, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg, int caps = 0x4444) {
+    return hybrid ? launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 2>(q, blocks, lds, stream, stride, cfg, chain_cfg, caps)
+                  : launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 0>(q, blocks, lds, stream, stride, cfg, chain_cfg, caps);
 }
 
 static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
@@ -1511,22 +1573,28 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
     // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
-    int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24) | (2 << 28);
+    int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
+    int caps = 4 | (4 << 4) | (4 << 8) | (4 << 12);     // pixels a chain wave holds while one of them comes from chain list 0 / 1 / 2 / 3
     int cfg = cull | (boost << 8) | (sparse_max << 16);
     static const bool chain_single = getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '1';     // experiments
+    static const bool single_ray = !(getenv("RT_SINGLE_RAY") && getenv("RT_SINGLE_RAY")[0] == '0');          // scan_single for waves with one live ray
+    static const int pool_env = getenv("RT_POOL") ? atoi(getenv("RT_POOL")) : 0;                             // experiments: pooled grabs of phase 2
     if (chain_single) cfg |= 2;
-    if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost,chain_pixels,chain_pixels_long"
-        int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 2;
-        sscanf(t, "%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g);
+    if (single_ray) cfg |= 4;
+    cfg |= ((pool_env / 4) & 0x1F) << 3;
+    if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost,chain_pixels,chain_pixels of list 0,1,2"
+        int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 4, g1 = 4, g2 = 4;
+        sscanf(t, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g, &g1, &g2);
         // every field is a bit-field of chain_cfg / cfg and some are divisors or loop bounds in the kernel: refuse what does not fit
-        if (a < 1 || a > 255 || b < 0 || b > kWavesPerWg || c < 1 || c > 255 || d < 0 || d > kCostClasses - 1 || e2 < 0 || e2 > 255 ||
-            f < 1 || f > 15 || g < 1 || g > 7) {
-            fprintf(stderr, "rt error: RT_TUNE=%s out of range (chain_every 1..255, chain_waves 0..%d, heavy_thr 1..255, n_chain 0..%d, boost 0..255, "
-                            "chain_pixels 1..15, chain_pixels_long 1..7)\n", t, kWavesPerWg, kCostClasses - 1);
+        if (a < 1 || a > 255 || b < 0 || b > kWavesPerWg || c < 1 || c > 255 || d < 0 || d > 15 || e2 < 0 || e2 > 255 ||
+            f < 1 || f > 15 || g < 1 || g > 15 || g1 < 1 || g1 > 15 || g2 < 1 || g2 > 15) {
+            fprintf(stderr, "rt error: RT_TUNE=%s out of range (chain_every 1..255, chain_waves 0..%d, heavy_thr 1..255, n_chain 0..15, boost 0..255, "
+                            "chain_pixels 1..15, chain_pixels of list 0 / 1 / 2 1..15)\n", t, kWavesPerWg);
             return hipErrorInvalidValue;
         }
-        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24) | (int)((unsigned)g << 28);
-        cfg = cull | (e2 << 8) | (sparse_max << 16) | (chain_single ? 2 : 0);
+        chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24);
+        caps = g | (g1 << 4) | (g2 << 8) | (f << 12);
+        cfg = cull | (e2 << 8) | (sparse_max << 16) | (chain_single ? 2 : 0) | (single_ray ? 4 : 0) | (((pool_env / 4) & 0x1F) << 3);
     }
     const unsigned nb = (unsigned)blocks;
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);
@@ -1561,7 +1629,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         q.phase = 2;
         e = wait_fb();
         if (e != hipSuccess) return e;
-        return launch_queue_kernel<2, 2, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
+        return launch_queue_kernel<2, 2, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg, caps);
     }
     bool classified = false;
     if ((order_mode == 0 || order_mode == 3) && p.order != nullptr) {

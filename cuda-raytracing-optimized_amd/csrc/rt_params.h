@@ -76,6 +76,7 @@ struct RtSphereParams {
     // two-phase rendering of the reference-stream mode (see rt_kernels_spheres.hip, "cost-ordered second phase"):
     int32_t phase;              // 0 = single launch; 1 = first samples [0, s_split) -> per-pixel state; 2 = resume [s_split, ns)
     int32_t s_split;            // samples rendered by phase 1
+    int32_t chain_top_thr;      // 16 x rays per sample from which a pixel goes to chain list 0 (the longest chains; see kChainClasses)
     float4* px_state;           // local_rows * nx: (col.xyz, rng bits) after phase 1
     uint32_t* px_rays;          // local_rows * nx: rays traced by phase 1
 };
