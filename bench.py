@@ -63,7 +63,9 @@ WORKLOADS = {
 
 
 # ------------------------------------------------------------------------------------------------------
-# communication: torch.distributed (nccl = RCCL on the GPU box, gloo in the CPU tests) or nothing at N = 1
+# communication: a barrier and max / sum of a few scalars over the ranks.  Default at N > 1: a file in /dev/shm
+# (cuda-raytracing-optimized_amd/multigpu.py ShmComm) - the job needs no RCCL on its data path (host gather) and none on
+# its control path either.  RT_BENCH_BACKEND=nccl | gloo selects torch.distributed instead (DistComm).
 # ------------------------------------------------------------------------------------------------------
 
 class LocalComm:
@@ -312,6 +314,19 @@ def cpu_baseline(w):
             "host_cpus": os.cpu_count()}
 
 
+def verify_gather(gathered, single, world, stripe=8):
+    """The image the ranks of an N > 1 job delivered into the shared framebuffer against the same frame rendered by ONE GPU: every stripe of
+    every rank, bit for bit (pixel seeds depend on the global pixel id only: the partition must be invisible)."""
+    g, s1 = np.ascontiguousarray(gathered).view(np.uint32), np.ascontiguousarray(single).view(np.uint32)
+    same_rows = (g == s1).all(axis=(1, 2))
+    ny = g.shape[0]
+    bad_stripes = sorted({int(r) // stripe for r in np.nonzero(~same_rows)[0]})
+    return {"gather_ok": bool(same_rows.all()) and not bool(np.isnan(gathered).any()),
+            "gather_check": f"whole {g.shape[1]}x{ny} image of the {world}-rank job, all {(ny + stripe - 1) // stripe} stripes, bit for bit against the "
+                            f"single-GPU render of the same frame (other_configs.single_gpu_same_workload); NaN-free",
+            "gather_bad_stripes": bad_stripes[:16], "gather_bad_ranks": sorted({k % world for k in bad_stripes})}
+
+
 def brief(job, extra=None):
     d = {"value": job["value"], "unit": "Msamples/s", "ms_per_step": job["ms_per_step"], "frame_ms_kernel": job["kernel_ms"],
          "steps": job["steps"], "rays_per_sample": job["counters"]["rays"] / job["samples"]}
@@ -347,19 +362,22 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
-    # One rank per GPU.  (Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_BACKEND=gloo maps the ranks onto the
-    # GPUs that exist, round robin, and does the barrier / max over gloo; the driver's runs use nccl = RCCL.)
-    backend_name = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend_name == "nccl" else local_rank % torch.cuda.device_count()
+    # One rank per GPU (on a box with fewer GPUs than ranks - a rehearsal - the ranks share the GPUs that exist, round robin).
+    backend_name = os.environ.get("RT_BENCH_BACKEND", "shm")
+    dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     comm = LocalComm()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend_name == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            comm = DistComm(dist, "cuda")
+        elif backend_name == "gloo":
+            dist.init_process_group(backend="gloo")
+            comm = DistComm(dist, "cpu")
         else:
-            dist.init_process_group(backend=backend_name)
-        comm = DistComm(dist, "cuda" if backend_name == "nccl" else "cpu")
+            from cuda_raytracing_optimized_amd import multigpu
+            comm = multigpu.ShmComm(rank, world)
 
     hip = HipBackend(args.fp, args.rng, args.variant)
     tag = f"bench_{os.environ.get('MASTER_PORT', '0')}"
@@ -375,6 +393,7 @@ def main():
         return w
 
     others = {}
+    gather = None
     if world == 1:
         w = with_overrides(WORKLOADS["C2"])
         job = run_job(hip, comm, w, args.steps, args.warmup, tag)
@@ -398,7 +417,7 @@ def main():
                                               "roofline": {k: v for k, v in sphere_roofline(j5, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic")}})
     else:
         w = with_overrides(WORKLOADS["C5"])
-        job = run_job(hip, comm, w, args.steps, args.warmup, tag, count_spp=4, warmup_spp=16)
+        job = run_job(hip, comm, w, args.steps, args.warmup, tag, count_spp=4, warmup_spp=16, keep_image=True)
         metric = f"Msamples/s (pixels x spp / s), random-spheres 3840x2160x{w['spp']}spp split over {world} GPUs (BASELINE.json configs[4])"
         scaling = "strong"
         partition = f"{world} x interleaved 8-row stripes of the fixed 3840x2160 image, host gather into one shared pinned framebuffer, no collective"
@@ -411,8 +430,9 @@ def main():
             # the same C5 frame on rank 0's GPU alone: this line's own strong-scaling denominator
             solo = None
             if rank == 0:
-                js = run_job(hip, LocalComm(), w, 1, 1, tag + "_solo", count_spp=4, warmup_spp=16)
+                js = run_job(hip, LocalComm(), w, 1, 1, tag + "_solo", count_spp=4, warmup_spp=16, keep_image=True)
                 solo = brief(js, {"workload": w["name"] + "; whole frame on rank 0's GPU alone while the other ranks wait"})
+                gather = verify_gather(job["image"], js["image"], world)
             comm.barrier()
             if solo:
                 others["single_gpu_same_workload"] = solo
@@ -430,6 +450,8 @@ def main():
             "executed_sphere_tests_per_ray": job["exec_tests_per_ray"],
             "roofline": roof,
         }
+        if world > 1:
+            out.update(gather if gather else {"gather_ok": None, "gather_check": "not run (--no-other-configs: no single-GPU render to compare with)"})
         if others:
             out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
@@ -437,7 +459,10 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.destroy_process_group()
+        if isinstance(comm, DistComm):
+            dist.destroy_process_group()
+        else:
+            comm.close()
 
 
 if __name__ == "__main__":

@@ -312,6 +312,24 @@ __device__ __forceinline__ bool hit_bbox(f3 bmin, f3 bmax, const Ray& r, float t
 
 // triangleHit, intersections.h:54-83.  `1.0 / a` there is a double divide narrowed to float, which
 // equals the correctly rounded float quotient (53 >= 2*24+2), so 1.0f / a is bit-identical.
+// ... on (v0, edge1, edge2): the mesh kernel's compact leaf records hold the two edges, rounded on the host exactly like the two subtractions below
+__device__ __forceinline__ float triangle_hit_edges(f3 v0, f3 edge1, f3 edge2, const Ray& r, float t_min, float t_max, float& hitU, float& hitV) {
+    const float EPS = 0.0000001f;
+    const f3 h = cross(r.d, edge2);
+    const float a = dot(edge1, h);
+    if (a > -EPS && a < EPS) return FLT_MAX;
+    const float f = 1.0f / a;
+    const f3 s = r.o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return FLT_MAX;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(r.d, q);
+    if (v < 0.0f || u + v > 1.0f) return FLT_MAX;
+    const float t = f * dot(edge2, q);
+    if (t > t_min && t < t_max) { hitU = u; hitV = v; return t; }
+    return FLT_MAX;
+}
+
 __device__ __forceinline__ float triangle_hit(f3 v0, f3 v1, f3 v2, const Ray& r, float t_min, float t_max, float& hitU, float& hitV) {
     const float EPS = 0.0000001f;
     const f3 edge1 = v1 - v0;

@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(kThreads) k_render_mesh(const RtMeshParams P) 
 //             bounce, the next sample, or the next pixel from the global queue (ballot + mbcnt allocation).
 // Lanes that are still traversing simply keep their state across a PROCESS phase.
 constexpr int kMinTraversing = 40;
+constexpr uint32_t kLeafCntLds = 32768;     // leaves whose triangle counts the default kernel keeps in the LDS (one byte each, beside its 5 KB of pair-round scratch)
 
 struct Job {
     Ray r;
@@ -325,10 +326,21 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     uint32_t* w_owner = s_owner + (threadIdx.x & ~63u);
     unsigned long long* w_best = s_best + (threadIdx.x & ~63u);
     float2* w_uv = s_uv + (threadIdx.x & ~63u);
-    const int pair_per = (TRAV == 0 && P.leaf_sentinels_trailing && P.nppl >= 1u && P.nppl <= 16u) ? (int)(64u / P.nppl) : 0;     // rays per pair round
+    // (pair rounds need the compact leaf records of the host - RtMeshParams::leaf_tri / leaf_ofs, built when no leaf has a real triangle behind a sentinel)
+    const int pair_per = (TRAV == 0 && P.leaf_sentinels_trailing && P.leaf_ofs != nullptr && P.leaf_tri != nullptr && P.nppl >= 1u && P.nppl <= 16u &&
+                          P.first_leaf <= kLeafCntLds) ? (int)(64u / P.nppl) : 0;     // rays per pair round
     const uint32_t pair_r = pair_per ? lane / P.nppl : 0u;
     const uint32_t pair_k = pair_per ? lane - pair_r * P.nppl : 0u;
     const bool pair_ok = pair_per && (int)pair_r < pair_per;
+    // Compact leaf records (rt_params.h): a pair lane reads the 48 bytes triangleHit needs (v0 and the two edges) of a REAL triangle only - the number
+    // of real triangles of every leaf sits in the LDS (one byte per leaf, staged once per workgroup), so the sentinel slots of a leaf (on the
+    // benchmark tree 2.8 of its 5) are never requested: 1.7 MB of triangle data touched instead of 5.2 MB.
+    extern __shared__ __align__(16) unsigned char s_leaf_cnt[];
+    if (pair_per > 0) {
+        const uint32_t words = (P.first_leaf + 3u) >> 2;
+        for (uint32_t k = threadIdx.x; k < words; k += kThreads) reinterpret_cast<uint32_t*>(s_leaf_cnt)[k] = P.leaf_ofs[k];
+        __syncthreads();
+    }
     const f3 lightC = ld3(P.light.center);
     const float lightR = P.light.radius;
     float* fbf = reinterpret_cast<float*>(P.fb);
@@ -649,25 +661,25 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                             const float o_closest = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.closest)));
                             const uint32_t o_packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)packed);
                             const bool o_shadow = (o_packed & 0x80000000u) != 0u;
-                            const uint32_t slot = ((o_packed & 0x7FFFFFFFu) - P.first_leaf) * P.nppl + pair_k;
                             bool reached = false, hit = false;
                             float u = 0.0f, v = 0.0f;
                             unsigned long long key = ~0ull;
-                            if (pv) {
-                                const float4* pt = reinterpret_cast<const float4*>(P.tris + slot);
-                                const float4 ta = pt[0], tb = pt[1];
-                                const float tcx = pt[2].x;
-                                reached = !isinf(ta.x);                  // kernels.cu:202 sentinel; sentinels are trailing (checked on the host)
-                                // the test runs on a sentinel too (its NaNs fail every compare -> FLT_MAX): behind `if (reached)` the compiler
-                                // issued the loads of tb / tcx only after ta had arrived - two memory round trips per pair round
-                                Ray pr;
-                                pr.o = F3(ox, oy, oz); pr.d = F3(dx, dy, dz); pr.inv = F3(0, 0, 0);
-                                const float hitT = triangle_hit(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tcx), pr, eps, o_closest, u, v);
-                                hit = reached && hitT < o_closest;
-                                if (hit) {
-                                    key = o_shadow ? (unsigned long long)pair_k
-                                                   : (((unsigned long long)__float_as_uint(hitT) << 32) | (unsigned long long)pair_k);
-                                    atomicMin(&w_best[owner], key);
+                            {
+                                const uint32_t o_leaf = (o_packed & 0x7FFFFFFFu) - P.first_leaf;
+                                reached = pv && pair_k < (uint32_t)s_leaf_cnt[pv ? o_leaf : 0u];     // kernels.cu:202: the loop ends at the leaf's first sentinel = after its real triangles
+                                if (reached) {
+                                    const float4* pt = P.leaf_tri + (size_t)(o_leaf * P.nppl + pair_k) * 3;
+                                    const float4 ta = pt[0], tb = pt[1];
+                                    const float tcx = pt[2].x;
+                                    Ray pr;
+                                    pr.o = F3(ox, oy, oz); pr.d = F3(dx, dy, dz); pr.inv = F3(0, 0, 0);
+                                    const float hitT = triangle_hit_edges(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tcx), pr, eps, o_closest, u, v);
+                                    hit = hitT < o_closest;
+                                    if (hit) {
+                                        key = o_shadow ? (unsigned long long)pair_k
+                                                       : (((unsigned long long)__float_as_uint(hitT) << 32) | (unsigned long long)pair_k);
+                                        atomicMin(&w_best[owner], key);
+                                    }
                                 }
                             }
                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -855,15 +867,16 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     // only: 8 -> 607, 12 -> 648, 16 -> 616, 24 -> 541 Msamples/s (round 1, with partial rounds: 16 -> 610).
     if (leaf_thr == 0) leaf_thr = (p.nppl >= 1u && p.nppl <= 16u) ? (int)(64u / p.nppl) : 16;
     const dim3 grid((unsigned)blocks), block(kThreads);
+    const size_t lds = (!classic && p.leaf_ofs && p.first_leaf <= kLeafCntLds) ? (size_t)((p.first_leaf + 15u) & ~15u) : 0;      // the leaf-count table
     // the counting instantiation (STATS: the reference's ray statistics as device atomics) runs only when counters are asked for
     if (classic) {
-        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<1, true, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
-        else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<1, false, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
-        else hipLaunchKernelGGL((k_render_mesh_queue<1, false, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<1, true, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
+        else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<1, false, true>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<1, false, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
     } else {
-        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
-        else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<0, false, true>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
-        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false>), grid, block, 0, stream, p, stride, min_traversing, leaf_thr);
+        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
+        else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<0, false, true>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
     }
     return hipGetLastError();
 }

@@ -405,7 +405,9 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
-    float4* w_ray = reinterpret_cast<float4*>(W);                               // 64 x 2 float4
+    float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r: (origin, a) at w_ray[r], (direction, -) at w_ray[64 + r] - two arrays of 16-byte
+                                                                                // entries: the pair lanes of a round fetch rays of (mostly) consecutive owners, and 16
+                                                                                // consecutive 16-byte entries cover all 64 banks once (32-byte entries: twice)
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);
     uint32_t* w_cand = reinterpret_cast<uint32_t*>(W + kWaveScratchPairs);
@@ -417,15 +419,15 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     // owner's slot with the (t, original index) key.  t_max = FLT_MAX: a root beyond the owner's current best loses the min anyway.
     auto resolve = [&](uint32_t e) {
         const int owner = (int)(e >> 24), k = (int)(e & 0xFFFFFFu);
-        const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
+        const float4 ro = w_ray[owner], rd = w_ray[64 + owner];
         const float t = sphere_hit_exact(S.sph[sidx(k)], F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, t_min, FLT_MAX);
         const int o = S.orig[k];
         if (o != 0x7fffffff && t < FLT_MAX)
             atomicMin(&w_best[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)o);
     };
 
-    w_ray[2 * lane] = make_float4(org.x, org.y, org.z, a);
-    w_ray[2 * lane + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
+    w_ray[lane] = make_float4(org.x, org.y, org.z, a);
+    w_ray[64 + lane] = make_float4(dn.x, dn.y, dn.z, 0.0f);
     w_best[lane] = ~0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // publishes the ray table and the zeroed candidate counter
     __builtin_amdgcn_wave_barrier();
@@ -514,7 +516,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 const int owner = (int)(pr >> 10);
                 const int slot0 = ((win_base + (int)(pr & 0x3FFu)) << kSphereGroupShift) + (lane & ((1 << ls) - 1)) * spl;
                 const int sbase = sidx(slot0);
-                const float4 ro = w_ray[2 * owner], rd = w_ray[2 * owner + 1];
+                const float4 ro = w_ray[owner], rd = w_ray[64 + owner];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
                 // A pair round only has to FIND the spheres whose discriminant (intersections.h:90-93: b*b - a*c, every product and sum rounded)
                 // is positive; their hits are then computed literally by resolve().  So the round evaluates -(b*b - a*c) with fused
@@ -642,7 +644,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
-    float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r at w_ray[2r], w_ray[2r + 1]
+    float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r at w_ray[r], w_ray[64 + r] (as in scan_pairs)
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);   // best key of ray r at w_best[r]
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);  // reachable (ray << 12 | group) pairs
     const bool mine = ((live >> lane) & 1ull) != 0ull;
@@ -650,8 +652,8 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
     const int my_r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
     float4* w_box = reinterpret_cast<float4*>(W + kWaveScratchPairs);           // the ray side of the box tests, 3 float4 per ray (<= 16 rays: the candidate list's space)
     if (mine) {
-        w_ray[2 * my_r] = make_float4(org.x, org.y, org.z, a);
-        w_ray[2 * my_r + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
+        w_ray[my_r] = make_float4(org.x, org.y, org.z, a);
+        w_ray[64 + my_r] = make_float4(dn.x, dn.y, dn.z, 0.0f);
         w_best[my_r] = ~0ull;
         const BoxRay b = make_box_ray(P, org, dn, 0.0f);             // once per ray (margin, reciprocals), not once per (ray, group) item
         w_box[3 * my_r] = make_float4(b.inv.x, b.inv.y, b.inv.z, 0.0f);
@@ -667,7 +669,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
         const int w = base + lane;
         if (w < m * nbs) {
             const int r = w / nbs, sl = w - r * nbs;
-            const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
+            const float4 ro = w_ray[r], rd = w_ray[64 + r];
             sparse_test_slot(P, S, sl, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, &w_best[r]);
         }
     }
@@ -712,7 +714,7 @@ __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneL
         if (w < (np << kSphereGroupShift)) {
             const unsigned pr = w_pair[w >> kSphereGroupShift];
             const int r = (int)(pr >> 12), g = (int)(pr & 0xFFFu);
-            const float4 ro = w_ray[2 * r], rd = w_ray[2 * r + 1];
+            const float4 ro = w_ray[r], rd = w_ray[64 + r];
             sparse_test_slot(P, S, (g << kSphereGroupShift) + (w & (kSphereGroup - 1)), F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), ro.w, &w_best[r]);
         }
     }
@@ -783,11 +785,28 @@ __device__ __forceinline__ Hit scan_single(const RtSphereParams& P, const SceneL
 
 // ---- shading of one hit / miss: the rest of color()'s loop body (kernels.cu:415-531) -------------------------------
 // Returns true when the path ended (the caller accumulates L.pcolor and starts the next sample).
+// The reference's `#ifdef STATS` ray statistics (kernels.cu:47-67,399-432,514-531) for sphere scenes, counted when P.counters is set (an untimed run): a
+// sphere scene's spheres are its "mesh" (the oracle counts them the same way), so SECONDARY_MESH = SECONDARY and SECONDARY_NOHIT = 0; there are no
+// scene-bounds, shadow or BVH statistics.  One device atomic per wave and event (hipcc folds the per-lane adds of a wave into one).  Compiled into the
+// counting / diagnostic instantiation of the persistent kernel only (STATS; the launcher takes it when counters are asked for): in the production one the
+// sites would cost registers.
+template <bool STATS>
+__device__ __forceinline__ void ray_stat(const RtSphereParams& P, int k) { if (STATS && P.counters) atomicAdd(&P.counters->ref_stats[k], 1ull); }
+
+template <bool STATS>
 __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S, Lane& L, f3 dn, Hit h) {
+    const bool primary = L.bounce == 0;
+    if (STATS && P.counters) {                                       // kernels.cu:403-408
+        ray_stat<STATS>(P, primary ? RT_STAT_PRIMARY : RT_STAT_SECONDARY);
+        if (!primary) ray_stat<STATS>(P, RT_STAT_SECONDARY_MESH);
+        if (len(L.atten) < 0.01f) ray_stat<STATS>(P, RT_STAT_LOW_POWER);
+    }
     if (h.sid < 0) {
+        ray_stat<STATS>(P, primary ? RT_STAT_PRIMARY_NOHITS : RT_STAT_SECONDARY_MESH_NOHIT);      // kernels.cu:414-417
         L.pcolor = L.pcolor + L.atten * sky_color(P.sky, L.dir);     // kernels.cu:419-425
         return true;
     }
+    if (primary) ray_stat<STATS>(P, RT_STAT_PRIMARY_HIT_MESH);              // kernels.cu:428-432
     const float4 sc4 = S.sph[sidx(h.sid)];
     const float radius = S.rad[h.sid];                               // slot-indexed, like every scene array on the device
     const f3 hp = L.org + h.closest * dn;                            // ray.h:12 point_at_parameter
@@ -804,14 +823,15 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
     if (P.rr && L.bounce > 3) {                                      // kernels.cu:512-527
         const float mx = max3(L.atten);
         if (rnd(L.rng) > mx) {
-            path_done = true;
+            ray_stat<STATS>(P, RT_STAT_RUSSIAN_KILL);
+            return true;                                             // kernels.cu:517-520 (the bounce counter no longer matters: the path is over)
         } else {
             const float kk = 1.0f / mx;
             L.atten = F3(L.atten.x * kk, L.atten.y * kk, L.atten.z * kk);
         }
     }
     L.bounce++;
-    if (L.bounce >= P.max_depth) path_done = true;                   // loop bound, kernels.cu:402
+    if (L.bounce >= P.max_depth) { ray_stat<STATS>(P, RT_STAT_EXCEED_MAX_BOUNCE); path_done = true; }     // loop bound, kernels.cu:402,529-531
     return path_done;
 }
 
@@ -819,7 +839,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // lanes must call it together.  With many live lanes each lane scans the sphere list for its own ray; with few
 // (the tail of a tile / of the frame, where a handful of glass-trapped pixels need thousands of rays each) the
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
-template <bool LEGACY>
+template <bool LEGACY, bool STATS = false>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
                                            uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
@@ -854,7 +874,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
         }
     }
     bool done = false;
-    if (has_ray) done = shade(P, S, L, dn, h);
+    if (has_ray) done = shade<STATS>(P, S, L, dn, h);
     lap(5);
     return done;
 }
@@ -1211,6 +1231,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     bool need_sample = false;
     auto finish = [&](bool fin, bool now) {
         if (fin) {
+            if (DBG && P.counters && (isnan(L.pcolor.x) || isnan(L.pcolor.y) || isnan(L.pcolor.z))) ray_stat<DBG>(P, RT_STAT_NAN);      // kernels.cu:559-561
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
             if (L.s < s_end) {
@@ -1241,7 +1262,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
 
     while (true) {
         // ---- refill idle lanes --------------------------------------------------------------------------------
-        const unsigned long long t_refill = (DBG && wdbg) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const bool dbg_timers = DBG && wdbg && (cfg & (1 << 29)) == 0;          // RT_WAVE_DEBUG_LIGHT=1: time stamps of waves and pixels only (the section timers
+                                                                                 // stretch a sparse step by 40 %: the light form keeps the frame's real proportions)
+        const unsigned long long t_refill = dbg_timers ? __builtin_amdgcn_s_memtime() : 0ull;
         while (!exhausted) {
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
@@ -1367,7 +1390,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         }
         if (need_sample) { start_sample(sample_params(), L); need_sample = false; }
         const unsigned long long live_now = __ballot(have_pixel);
-        if (DBG && wdbg) dbg_tm[7] += __builtin_amdgcn_s_memtime() - t_refill;
+        if (dbg_timers) dbg_tm[7] += __builtin_amdgcn_s_memtime() - t_refill;
         if (live_now == 0ull) break;                                 // wave-uniform exit: idle lanes stay to help
         if (wdbg) {
             if (exhausted && dbg_tex == 0ull) dbg_tex = __builtin_amdgcn_s_memrealtime();
@@ -1400,8 +1423,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             }
             if (sel) { nrays++; pix_rays++; }
             if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            const bool done = trace_rays<false>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, (DBG && wdbg) ? dbg_tm : nullptr, (cfg & 4) != 0);
-            if (DBG && wdbg) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
+            const bool done = trace_rays<false, DBG>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
+            if (dbg_timers) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel, steps > 1);
         }
     }
@@ -1482,13 +1505,14 @@ static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned b
 template <int PHASE, int CLS, bool CHUNKED, int SCENE>
 static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg, int caps) {
     // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
-    const void* kern = q.wave_dbg ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>)
+    const bool counting = q.wave_dbg != nullptr || q.counters != nullptr;          // the diagnostic instantiation also counts the reference's ray statistics
+    const void* kern = counting ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>)
                                   : reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (q.wave_dbg) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
+    if (counting) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
     else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
     return hipGetLastError();
 }
@@ -1582,6 +1606,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     if (chain_single) cfg |= 2;
     if (single_ray) cfg |= 4;
     cfg |= ((pool_env / 4) & 0x1F) << 3;
+    static const bool dbg_light = getenv("RT_WAVE_DEBUG_LIGHT") && getenv("RT_WAVE_DEBUG_LIGHT")[0] == '1';
+    if (dbg_light) cfg |= 1 << 29;
     if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost,chain_pixels,chain_pixels of list 0,1,2"
         int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 4, g1 = 4, g2 = 4;
         sscanf(t, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g, &g1, &g2);
@@ -1594,7 +1620,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         }
         chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24);
         caps = g | (g1 << 4) | (g2 << 8) | (f << 12);
-        cfg = cull | (e2 << 8) | (sparse_max << 16) | (chain_single ? 2 : 0) | (single_ray ? 4 : 0) | (((pool_env / 4) & 0x1F) << 3);
+        cfg = cull | (e2 << 8) | (sparse_max << 16) | (chain_single ? 2 : 0) | (single_ray ? 4 : 0) | (((pool_env / 4) & 0x1F) << 3) | (dbg_light ? (1 << 29) : 0);
     }
     const unsigned nb = (unsigned)blocks;
     const unsigned cls_blocks = (unsigned)((total_px + kThreads - 1) / kThreads);

@@ -90,6 +90,10 @@ struct RtMeshParams {
                                 // {min_L, min_R, max_L, max_R | max_L, max_R, min_L, min_R} (L = node 2i, R = node 2i+1): a ray reads one float4 per
                                 // axis, the first (1/dir >= 0) or the second (1/dir < 0), and gets (near_L, near_R, far_L, far_R) - the swap of
                                 // intersections.h:30 done by the address (default kernel only)
+    const float4* leaf_tri;     // compact leaf records for the pair rounds of the default kernel: per triangle SLOT (leaf x nppl + k) 3 float4 = (v0.xyz, e1.x | e1.yz, e2.xy |
+                                // e2.z, -, -, -) with e1 = v1 - v0, e2 = v2 - v0 rounded as intersections.h:56-57 rounds them; sentinel slots are zero and never read;
+                                // nullptr = not built (a leaf with a real triangle behind a sentinel)
+    const uint32_t* leaf_ofs;   // number of real triangles of every leaf, one BYTE per leaf (packed four to a word; staged into the LDS by the kernel)
     uint32_t first_leaf;
     uint32_t nppl;
     int32_t leaf_sentinels_trailing;   // host-checked: no real triangle behind a sentinel in any leaf (pair rounds allowed)

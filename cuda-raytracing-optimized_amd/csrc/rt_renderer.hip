@@ -63,6 +63,8 @@ struct DeviceState {
     rt_triangle* d_tris = nullptr;
     float4* d_bvh = nullptr;
     float* d_bvh_axis = nullptr;
+    float4* d_leaf_tri = nullptr;
+    uint32_t* d_leaf_ofs = nullptr;
     rt_material* d_materials = nullptr;
     std::vector<float*> d_tex;
     float** d_tex_data = nullptr;
@@ -105,6 +107,8 @@ struct RenderContext {
     std::vector<rt_triangle> h_tris;
     std::vector<float4> h_bvh;          // numBvhNodes * 24 B viewed as float4 (padded)
     std::vector<float> h_bvh_axis;      // RtMeshParams::bvh_axis
+    std::vector<float4> h_leaf_tri;     // RtMeshParams::leaf_tri (empty = not built: sentinels inside leaves, or more than 16 M triangles)
+    std::vector<uint32_t> h_leaf_ofs;   // RtMeshParams::leaf_ofs
     int num_bvh_nodes = 0;
     int nppl = 0;
     int leaf_sentinels_trailing = 1;
@@ -153,7 +157,7 @@ void free_device(DeviceState& d) {
     if (d.stream) HIP_CHECK(hipStreamSynchronize(d.stream));
     auto fr = [](void* p) { if (p) HIP_CHECK(hipFree(p)); };
     fr(d.d_spheres); fr(d.d_rad); fr(d.d_mat_color); fr(d.d_mat_type); fr(d.d_groups); fr(d.d_orig); fr(d.d_slot_of);
-    fr(d.d_tris); fr(d.d_bvh); fr(d.d_bvh_axis); fr(d.d_materials);
+    fr(d.d_tris); fr(d.d_bvh); fr(d.d_bvh_axis); fr(d.d_leaf_tri); fr(d.d_leaf_ofs); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
     fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays);
@@ -220,6 +224,8 @@ void setup_devices() {
             d.d_tris = upload(c.h_tris);
             d.d_bvh = upload(c.h_bvh);
             d.d_bvh_axis = upload(c.h_bvh_axis);
+            d.d_leaf_tri = upload(c.h_leaf_tri);
+            d.d_leaf_ofs = upload(c.h_leaf_ofs);
             d.d_materials = upload(c.h_materials);
             const int nt = (int)c.h_tex.size();
             if (nt > 0) {
@@ -510,6 +516,29 @@ void initRenderer(const rt_kernel_scene sc, const rt_camera cam, rt_vec3** fb, i
             seen = seen || sent;
         }
     }
+    // Compact leaf records for the pair rounds (rt_params.h, leaf_tri / leaf_ofs): what triangleHit reads of a triangle and nothing else - v0 and the
+    // two edges, e1 = v1 - v0 and e2 = v2 - v0 computed here with the same single fp32 subtraction per component as intersections.h:56-57 (same bits) -
+    // for the REAL triangles only.  The caller's 64-byte array stays the ABI of this boundary (helper_structs.h:81-96) and is what a closest hit re-reads.
+    c.h_leaf_tri.clear(); c.h_leaf_ofs.clear();
+    if (c.leaf_sentinels_trailing && c.nppl <= 255) {
+        c.h_leaf_tri.assign((size_t)first_leaf * c.nppl * 3, make_float4(0, 0, 0, 0));
+        c.h_leaf_ofs.assign(((size_t)first_leaf + 3) / 4, 0u);
+        for (uint32_t leaf = 0; leaf < first_leaf; leaf++) {
+            uint32_t cnt = 0;
+            for (int k = 0; k < c.nppl; k++) {
+                const rt_triangle& t = c.h_tris[(size_t)leaf * c.nppl + k];
+                if (std::isinf(t.v[0].e[0])) break;
+                volatile float e1[3], e2[3];                         // (volatile: one rounded fp32 subtraction each, never a contracted or widened form)
+                for (int a = 0; a < 3; a++) { e1[a] = t.v[1].e[a] - t.v[0].e[a]; e2[a] = t.v[2].e[a] - t.v[0].e[a]; }
+                float4* rec = c.h_leaf_tri.data() + ((size_t)leaf * c.nppl + k) * 3;
+                rec[0] = make_float4(t.v[0].e[0], t.v[0].e[1], t.v[0].e[2], e1[0]);
+                rec[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+                rec[2] = make_float4(e2[2], 0.0f, 0.0f, 0.0f);
+                cnt++;
+            }
+            c.h_leaf_ofs[leaf >> 2] |= cnt << (8 * (leaf & 3));
+        }
+    }
     c.bounds = sc.m->bounds;
     c.floor = sc.floor;
     c.h_materials.assign(sc.materials, sc.materials + sc.numMaterials);                        // kernels.cu:617-618
@@ -674,6 +703,8 @@ void runRenderer(int ns, int tx, int ty) {
             memset(&p, 0, sizeof p);
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
             p.tris = d.d_tris; p.bvh4 = d.d_bvh; p.bvh_axis = d.d_bvh_axis;
+            static const bool compact_leaves = !(getenv("RT_COMPACT_LEAVES") && getenv("RT_COMPACT_LEAVES")[0] == '0');        // A/B
+            p.leaf_tri = compact_leaves ? d.d_leaf_tri : nullptr; p.leaf_ofs = compact_leaves ? d.d_leaf_ofs : nullptr;
             p.first_leaf = (uint32_t)c.num_bvh_nodes / 2; p.nppl = (uint32_t)c.nppl; p.bounds = c.bounds;
             p.leaf_sentinels_trailing = c.leaf_sentinels_trailing;
             p.materials = d.d_materials;

@@ -441,3 +441,57 @@ def test_far_camera_culling_is_still_exact(rt, O, dist, vfov):
         got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50, counters=1, variant=variant)
         assert np.array_equal(_bits(got), _bits(ref)), (variant, np.count_nonzero(_bits(got) != _bits(ref)))
         assert st.rays == cnt.rays
+
+
+@pytest.mark.parametrize("scene,rr", [("three", 0), ("random", 0), ("random", 1)])
+def test_reference_stats_counters_for_sphere_scenes(rt, O, scene, rr):
+    """The reference's `#ifdef STATS` ray statistics (kernels.cu:47-67,399-432,514-531) on SPHERE scenes, getRenderStats().ref_stats against the oracle's
+    count: primary / secondary rays, hits and misses by kind, low-power rays, paths cut at maxDepth, Russian-roulette kills, NaN samples - through the
+    single dispatch (4 spp) and the two-dispatch cost-ordered frame (12 spp).  maxDepth 6 makes EXCEED_MAX_BOUNCE common."""
+    nx, ny = 160, 96
+    sp, mt, cam = rt.scene_three_spheres(nx, ny) if scene == "three" else rt.scene_random_spheres(nx, ny)
+    for ns, depth in ((4, 50), (12, 6)):
+        o = O.default_options(True)
+        o.rr = rr
+        ref, cnt = O.render(O.sphere_scene(sp, mt), cam, o, nx, ny, ns, depth, counters=True)
+        got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, depth, counters=1, rr=rr)
+        assert np.array_equal(_bits(got), _bits(ref))
+        for k in range(18):
+            assert int(st.ref_stats[k]) == int(cnt.ref_stats[k]), (ns, depth, rt.RT_STAT_NAMES[k], int(st.ref_stats[k]), int(cnt.ref_stats[k]))
+        assert st.ref_stats[rt.RT_STAT_PRIMARY] == nx * ny * ns and st.ref_stats[rt.RT_STAT_PRIMARY] + st.ref_stats[rt.RT_STAT_SECONDARY] == st.rays
+        assert st.ref_stats[rt.RT_STAT_SECONDARY_MESH] == st.ref_stats[rt.RT_STAT_SECONDARY] and st.ref_stats[rt.RT_STAT_SECONDARY_NOHIT] == 0
+        if depth == 6:
+            assert st.ref_stats[rt.RT_STAT_EXCEED_MAX_BOUNCE] > 0
+        if rr and depth == 50:
+            assert st.ref_stats[rt.RT_STAT_RUSSIAN_KILL] > 0
+
+
+def test_statistical_parity_of_the_other_modes_against_a_converged_image(rt):
+    """the modes that are NOT bit-exact - the counter RNG stream (another, equally valid sequence of samples) and the FAST fp build (same
+    stream, chaotic fp divergence) - are held to the metric main.cpp:108-128 uses: RMSE against a converged image.  The converged image is the
+    reference stream in the PARITY build at 16384 spp (bit-identical to the oracle / the reference's arithmetic by every other test of this file).
+    Every mode's RMSE against it must fall like 1 / sqrt(n) and stay within 13 % of the reference stream's own RMSE at the same n: the modes
+    estimate the same image with the same variance.  (The reference stream's n-spp image is a PREFIX of the converged one, an independent stream's is
+    not: sqrt(1/n + 1/N) against sqrt(1/n - 1/N) is +6.5 % at n = 1024, N = 16384 by itself.  Measured: 1.3 / 2.4 / 9.3 % for the counter stream,
+    0.5 / 0.5 / 0.7 % for the FAST build.)"""
+    nx, ny = 160, 96
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, 50)
+    o = rt.getDefaultRenderOptions(True)
+
+    def render(ns, **kw):
+        rt.setRenderOptions(o, rng=kw.get("rng", rt.RT_RNG_REFERENCE_STREAM), fp=kw.get("fp", rt.RT_FP_PARITY))
+        rt.runRenderer(ns, 8, 8)
+        return np.array(fb, copy=True)
+    converged = render(16384)
+    rows = {}
+    for name, kw in (("reference", {}), ("counter", dict(rng=rt.RT_RNG_COUNTER)), ("fast", dict(fp=rt.RT_FP_FAST)),
+                     ("fast+counter", dict(rng=rt.RT_RNG_COUNTER, fp=rt.RT_FP_FAST))):
+        rows[name] = [rt.rmse(render(n, **kw), converged) for n in (64, 256, 1024)]
+    rt.cleanupRenderer()
+    print("RMSE vs the 16384-spp reference-stream image at 64 / 256 / 1024 spp:", {k: [round(x, 5) for x in v] for k, v in rows.items()})
+    ref = rows["reference"]
+    assert 1.7 < ref[0] / ref[1] < 2.3 and 1.6 < ref[1] / ref[2] < 2.4           # ~ 1 / sqrt(n) (the 1024-spp image shares its samples with the converged one)
+    for name in ("counter", "fast", "fast+counter"):
+        for k in range(3):
+            assert abs(rows[name][k] / ref[k] - 1.0) < 0.13, (name, k, rows[name][k], ref[k])

@@ -102,6 +102,51 @@ def test_bench_run_job_partitions_and_gathers_the_single_process_image(tmp_path,
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_fb_test_")]   # the shared framebuffer is unlinked
 
 
+def _shm_worker(rank, world, port, w, out_path):
+    """The same job with bench.py's DEFAULT communication at N > 1: barrier and max / sum through /dev/shm (multigpu.ShmComm), no torch.distributed."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_PORT"] = str(port)
+    import bench
+    from cuda_raytracing_optimized_amd import multigpu
+    comm = multigpu.ShmComm(rank, world, timeout=120.0)
+    assert comm.reduce([rank, 10 * rank, 1.5], "sum") == [sum(range(world)), 10 * sum(range(world)), 1.5 * world]
+    assert comm.reduce([rank, -rank], "max") == [world - 1, 0]
+    job = bench.run_job(OracleBackend(), comm, w, steps=2, warmup=1, tag=f"test_{port}", keep_image=True)
+    if rank == 0:
+        np.save(out_path, job["image"])
+        np.save(out_path + ".cnt.npy", np.array([job["counters"]["rays"], job["counters"]["prim_tests"], job["value"], job["elapsed"]]))
+    comm.close()
+
+
+@pytest.mark.parametrize("world,nx,ny", [(2, 64, 44), (4, 48, 72)])
+def test_bench_run_job_over_the_shm_barrier(tmp_path, world, nx, ny, rt, O):
+    """bench.py --gpus N as the driver launches it uses no RCCL at all: the framebuffer is gathered on the host and the barrier / reductions
+    of the timing go through a /dev/shm file.  Same job, same checks as the gloo variant above, plus bench.verify_gather()."""
+    import bench
+    w = dict(kind="spheres", nx=nx, ny=ny, spp=2, depth=50, name="test")
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_shm_worker, args=(world, _free_port(), w, out), nprocs=world, join=True)
+    got = np.load(out)
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, 2, 50, counters=True)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    rays, tests, value, elapsed = np.load(out + ".cnt.npy")
+    assert rays == cnt.rays and tests == cnt.prim_tests
+    assert elapsed > 0 and abs(value - nx * ny * 2 * 2 / elapsed / 1e6) < 1e-9 * value
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_fb_test_") or f.startswith("rt_comm_")]      # both shared files are unlinked
+    # the N > 1 line's image check: the gathered image against a single-GPU render, stripe by stripe
+    v = bench.verify_gather(got, ref, world)
+    assert v["gather_ok"] is True and v["gather_bad_stripes"] == []
+    broken = got.copy()
+    broken[8 * 3 + 2, 5, 1] += 1.0                        # one pixel of stripe 3 (rank 3 % world)
+    v = bench.verify_gather(broken, ref, world)
+    assert v["gather_ok"] is False and v["gather_bad_stripes"] == [3] and v["gather_bad_ranks"] == [3 % world]
+    broken = got.copy()
+    broken[0, 0, 0] = np.nan                              # a lost pixel (the renderer poisons the framebuffer with NaN before each frame)
+    assert bench.verify_gather(broken, broken, world)["gather_ok"] is False
+
+
 def test_run_job_single_rank_needs_no_shared_framebuffer(rt, O):
     import bench
     w = dict(kind="spheres", nx=32, ny=24, spp=1, depth=50, name="test")
