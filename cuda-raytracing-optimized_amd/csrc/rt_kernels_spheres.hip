@@ -54,7 +54,7 @@ using namespace rtd;
 
 namespace {
 
-constexpr int kWavesPerWg = 8;              // 8 waves share one LDS copy of the scene (tile kernel: 8 tiles side by side, 64 x 8 pixels)
+constexpr int kWavesPerWg = 16;             // 16 waves - a whole CU at 4 waves per SIMD - share ONE LDS copy of the scene (tile kernel: 16 tiles side by side)
 constexpr int kThreads = 64 * kWavesPerWg;
 
 constexpr int kPassGroups = 16;
@@ -123,9 +123,9 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
     if (SCENE == 2) {
         int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups);
-        for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += kThreads) s_sph[k] = P.spheres[k];
-        for (int k = threadIdx.x; k < P.n_padded; k += kThreads) s_org[k] = P.orig[k];
-        for (int k = threadIdx.x; k < 3 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
+        for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += (int)blockDim.x) s_sph[k] = P.spheres[k];
+        for (int k = threadIdx.x; k < P.n_padded; k += (int)blockDim.x) s_org[k] = P.orig[k];
+        for (int k = threadIdx.x; k < 3 * P.n_groups; k += (int)blockDim.x) s_grp[k] = P.groups[k];
         *after = nullptr;
         unsigned char* scratch = reinterpret_cast<unsigned char*>(s_org + P.n_padded);
         __syncthreads();
@@ -136,15 +136,15 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     int*    s_org = s_typ + P.n_padded;
     float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
     int*    s_sof = reinterpret_cast<int*>(s_rad + P.n_padded);
-    for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += kThreads) s_sph[k] = P.spheres[k];   // the image is laid out for the LDS on the host
-    for (int k = threadIdx.x; k < P.n_padded; k += kThreads) {
+    for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += (int)blockDim.x) s_sph[k] = P.spheres[k];   // the image is laid out for the LDS on the host
+    for (int k = threadIdx.x; k < P.n_padded; k += (int)blockDim.x) {
         s_rad[k] = P.rad[k];
         s_mat[k] = P.mat_color[k];
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
     }
-    for (int k = threadIdx.x; k < 3 * P.n_groups; k += kThreads) s_grp[k] = P.groups[k];
-    for (int k = threadIdx.x; k < P.n; k += kThreads) s_sof[k] = P.slot_of[k];
+    for (int k = threadIdx.x; k < 3 * P.n_groups; k += (int)blockDim.x) s_grp[k] = P.groups[k];
+    for (int k = threadIdx.x; k < P.n; k += (int)blockDim.x) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
     *after = s_fb;                                                   // WITH_FB (tile kernel): kThreads x 3 floats of framebuffer staging
     unsigned char* scratch = reinterpret_cast<unsigned char*>(s_fb + (WITH_FB ? kThreads * 3 : 0));
@@ -1167,7 +1167,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] - nA : padded;       // pixels in the general queue
         const uint32_t n_rest = total_px - n0;
         // lanes that draw from the general queue at t = 0: all, minus the chain waves (which start on the chain lists)
-        uint32_t spread = gridDim.x * (uint32_t)kThreads;
+        uint32_t spread = gridDim.x * blockDim.x;
         if (nA > 0u) spread -= ((gridDim.x + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u;
         s_q[0] = nA; s_q[1] = n0; s_q[2] = total_px * (CHUNKED ? (uint32_t)P.chunks : 1u); s_q[3] = spread;
         s_q[4] = (n0 > 0u && n0 <= spread && (spread - n0) <= n_rest) ? 1u : 0u;
@@ -1437,7 +1437,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     }
     if (wdbg) atomicMax(wdbg + 65536ull * 8 - 1, (unsigned long long)dbg_maxpix);      // longest pixel chain of the frame
     if (wdbg && (threadIdx.x & 63) == 0) {
-        unsigned long long* w = wdbg + ((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 8;
+        unsigned long long* w = wdbg + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
         w[0] = dbg_t0; w[1] = dbg_tex; w[2] = __builtin_amdgcn_s_memrealtime();
         w[3] = dbg_iters; w[4] = dbg_coop_iters; w[5] = dbg_coop_rays;
         w[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
@@ -1469,11 +1469,11 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 }
 }  // namespace
 
-static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0) {
+static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg) {
     // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
     const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48;
-    const size_t scratch = (size_t)kWavesPerWg * kWaveScratch;
+    const size_t scratch = (size_t)waves * kWaveScratch;
     if (scene == 1) return scratch;
     if (scene == 2) return test_data + (size_t)n_padded * 4 + scratch;
     return test_data + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
@@ -1482,7 +1482,7 @@ static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0) {
 
 #if defined(RT_MODE_PARITY)
 size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {                       // of the smallest LDS-resident form: beyond it the scene is read from global memory
-    return lds_bytes(n_padded, n, false, 2);
+    return lds_bytes(n_padded, n, false, 2, 8);
 }
 #endif
 
@@ -1502,6 +1502,8 @@ static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned b
     return hipGetLastError();
 }
 
+static int g_queue_threads = kThreads;      // workgroup size of the persistent kernel for the scene being launched (launch_spheres: 16 waves, or 8 when only that fits)
+
 template <int PHASE, int CLS, bool CHUNKED, int SCENE>
 static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg, int caps) {
     // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
@@ -1512,8 +1514,8 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (counting) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
-    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, caps);
+    if (counting) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
+    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
     return hipGetLastError();
 }
 
@@ -1542,12 +1544,21 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     const bool legacy = cb_bits != 0 && cb_bits != 255;
     if (legacy) kind = 1;                       // the brute-force A/B scans live in the tile kernel only
     if (p.global_scene) kind = 0;               // scenes beyond the LDS: the persistent kernel only
-    const size_t lds_full = lds_bytes(p.n_padded, p.n, kind == 1), lds_hybrid = lds_bytes(p.n_padded, p.n, false, 2);
     const size_t kLdsPerCu = 160 * 1024;
-    if (lds_full > kLdsPerCu) kind = 0;         // the tile kernel only knows the full copy
-    // the persistent kernel takes the hybrid copy when that puts more workgroups on a CU (two instead of one: 500..1700 spheres) or when the full one does not fit
-    const bool hybrid = kind == 0 && !p.global_scene && (lds_full > kLdsPerCu || (lds_full > kLdsPerCu / 2 && lds_hybrid <= kLdsPerCu / 2));
-    const size_t lds = hybrid ? lds_hybrid : lds_full;
+    if (lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) > kLdsPerCu) kind = 0;        // the tile kernel only knows the full copy
+    // The persistent kernel's workgroup is a whole CU's worth of waves (16: the launch bound's 4 per SIMD) around ONE scene copy - 88 KB of per-wave scratch
+    // leave 72 KB for the scene: the full copy up to ~1200 spheres (60 bytes per sphere), the hybrid one (what a sphere TEST reads in the LDS, what only a HIT
+    // reads in global memory: 21 bytes per sphere) up to ~3400; an 8-wave workgroup (44 KB of scratch, 2 waves per SIMD) keeps the hybrid copy resident up to
+    // ~5500 spheres; beyond that the same kernel reads the scene from global memory (p.global_scene, decided by the renderer with the same formula).
+    int waves = kWavesPerWg;
+    bool hybrid = false;
+    if (kind == 0 && !p.global_scene) {
+        if (lds_bytes(p.n_padded, p.n, false, 0, 16) <= kLdsPerCu) { hybrid = false; waves = 16; }
+        else if (lds_bytes(p.n_padded, p.n, false, 2, 16) <= kLdsPerCu) { hybrid = true; waves = 16; }
+        else { hybrid = true; waves = 8; }
+    }
+    g_queue_threads = 64 * waves;
+    const size_t lds = kind == 1 ? lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) : lds_bytes(p.n_padded, p.n, false, hybrid ? 2 : 0, waves);
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
     // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
     const int pb = (variant >> 27) & 7;
@@ -1576,18 +1587,18 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 2;      // = the residency the kernel's launch bound (4 waves/SIMD, 128 VGPRs) and LDS (~70 KB per workgroup) allow
+    if (wg_per_cu == 0) wg_per_cu = 1;      // one workgroup = the residency the kernel's launch bound (4 waves/SIMD, 128 VGPRs) and the LDS allow
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
-    const long long useful = (total_px + kThreads - 1) / kThreads;      // never more lanes than pixels
+    const long long useful = (total_px + g_queue_threads - 1) / g_queue_threads;      // never more lanes than pixels
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
     // scattered order: stride ~ 0.618 * total, coprime with total
     uint32_t stride = 1;
     int order_mode = (variant >> 24) & 3;
-    // A scene copy above 80 KB leaves ONE workgroup per CU (two waves per SIMD): there the coherent waves of the tile-major single dispatch beat the
-    // cost-ordered two dispatches (tools/sweep_scene_sizes.py, 1200x800x50: 900 spheres 2518 against 2483, 1100: 2269 / 2113, 1500: 1948 / 1591).
-    if (order_mode == 0 && !p.global_scene && lds > 80 * 1024) order_mode = 1;
+    // Scenes whose hit data (hybrid copy) or whole scene (global) is read from global memory: the scattered single dispatch beats the cost-ordered two
+    // dispatches (tools/sweep_scene_sizes.py, 1200x800x50, 16-wave workgroups: 1500 spheres 2819 against 2751, 2000: 2113 / 1696, 2600: 1812 / 1149).
+    if (order_mode == 0 && (hybrid || p.global_scene)) order_mode = 2;
     if (order_mode != 1 && total_px > 64) {
         auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
         unsigned long long cand = (unsigned long long)((double)total_px * 0.6180339887) | 1ull;
@@ -1597,7 +1608,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
     // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
-    int chain_cfg = 1 | (1 << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
+    int chain_cfg = 1 | ((waves / 8) << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
     int caps = 4 | (4 << 4) | (4 << 8) | (4 << 12);     // pixels a chain wave holds while one of them comes from chain list 0 / 1 / 2 / 3
     int cfg = cull | (boost << 8) | (sparse_max << 16);
     static const bool chain_single = getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '1';     // experiments
@@ -1609,10 +1620,10 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     static const bool dbg_light = getenv("RT_WAVE_DEBUG_LIGHT") && getenv("RT_WAVE_DEBUG_LIGHT")[0] == '1';
     if (dbg_light) cfg |= 1 << 29;
     if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost,chain_pixels,chain_pixels of list 0,1,2"
-        int a = 1, b = 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 4, g1 = 4, g2 = 4;
+        int a = 1, b = waves / 8, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 4, g1 = 4, g2 = 4;
         sscanf(t, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g, &g1, &g2);
         // every field is a bit-field of chain_cfg / cfg and some are divisors or loop bounds in the kernel: refuse what does not fit
-        if (a < 1 || a > 255 || b < 0 || b > kWavesPerWg || c < 1 || c > 255 || d < 0 || d > 15 || e2 < 0 || e2 > 255 ||
+        if (a < 1 || a > 255 || b < 0 || b > waves || c < 1 || c > 255 || d < 0 || d > 15 || e2 < 0 || e2 > 255 ||
             f < 1 || f > 15 || g < 1 || g > 15 || g1 < 1 || g1 > 15 || g2 < 1 || g2 > 15) {
             fprintf(stderr, "rt error: RT_TUNE=%s out of range (chain_every 1..255, chain_waves 0..%d, heavy_thr 1..255, n_chain 0..15, boost 0..255, "
                             "chain_pixels 1..15, chain_pixels of list 0 / 1 / 2 1..15)\n", t, kWavesPerWg);

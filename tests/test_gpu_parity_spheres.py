@@ -391,9 +391,10 @@ def _big_scene(rt, rng, n):
 
 @pytest.mark.parametrize("n,nx,ny,ns", [(2100, 96, 64, 9), (4000, 96, 64, 4), (20000, 48, 32, 4)])
 def test_scene_sizes_up_to_20000_spheres(rt, O, n, nx, ny, ns):
-    """No size cliff (the reference's scan takes any list, intersections.h:85-104): 2100 spheres still live in the
-    LDS (one 8-wave workgroup per CU), 4000 and 20000 are read from global memory by the same kernel - window-relative pair
-    entries beyond 1024 groups, single dispatch.  Bit-exact against the oracle, equal ray counts, culling on and off."""
+    """Scenes of any size (the reference's scan takes any list, intersections.h:85-104), one per scene form of the persistent kernel beyond the full LDS
+    copy: 2100 spheres - the hybrid copy (what a sphere test reads in the LDS, what only a hit reads in global memory) under a 16-wave workgroup;
+    4000 - the hybrid copy under an 8-wave workgroup (its 44 KB of scratch leave room for 96 KB of test data); 20000 - every array read from global
+    memory, window-relative pair entries beyond 1024 groups.  All single dispatch.  Bit-exact against the oracle, equal ray counts, culling on and off."""
     rng = np.random.default_rng(5 + n)
     sp, mt = _big_scene(rt, rng, n)
     cam = rt.make_camera((9, 3, 7), (0, 0, 0), (0, 1, 0), 35.0, nx / ny, 0.05, 10.0)
