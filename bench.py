@@ -14,8 +14,10 @@ per step; scene and camera already resident in HBM).
           4096 spp (34 G samples per step: 4.2 s on one GPU, ~0.5 s on eight).  The image is cut into
           interleaved 8-row stripes, rank r renders stripes k = r (mod N) — no collective on the data
           path — and the stripes are gathered on the host: the ranks share one framebuffer in /dev/shm,
-          page-locked by every rank, and each rank's device-to-host stripe copies (hipMemcpy2DAsync
-          inside runRenderer) land in it directly.  The same partitioned job on C2 (1200x800x100: 2 ms
+          page-locked by every rank, and each rank's finished pixels (stored by the kernel itself, over
+          the bus) land in it directly.  The barrier and the max / sum of the timing go through /dev/shm
+          too (multigpu.ShmComm): no RCCL anywhere.  The line carries "gather_ok": the shared framebuffer
+          equals rank 0's single-GPU render of the same frame bit for bit.  The same partitioned job on C2 (1200x800x100: 2 ms
           of kernel per GPU at N = 8, i.e. launch + D2H) is recorded under "other_configs" for the
           north star's "1200x800x100 at 1/2/4/8 GPUs", and rank 0 renders the whole C5 frame alone
           once ("single_gpu_same_workload") so the line carries its own strong-scaling denominator.
@@ -24,8 +26,8 @@ per step; scene and camera already resident in HBM).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 
 run_job() below is THE partitioned job: stripe partition, shared host framebuffer, barrier-bracketed
-timing, max/sum over ranks.  tests/test_multigpu_gloo.py drives this same function on CPU (gloo,
-world size 2 and 3) with a backend that renders the stripes with the CPU oracle.
+timing, max/sum over ranks.  tests/test_multigpu_gloo.py drives this same function on CPU (world sizes
+2-4, over the /dev/shm communicator and over gloo) with a backend that renders the stripes with the CPU oracle.
 """
 import argparse
 import hashlib

@@ -610,7 +610,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
 }
 
 // ---- closest hit, SPARSE form: at most kSparseRays live rays in the wave ----------------------------------------------
-// The tail of the frame belongs to a handful of pixels whose paths are trapped inside glass for up to maxDepth bounces
+// The tail of the frame belongs to a handful of pixels whose paths bounce up to maxDepth times in the wedge where a sphere rests on the ground
 // (thousands of rays, strictly sequential because of the per-pixel RNG stream).  For them the latency of ONE ray is what
 // counts, so the wave spends all 64 lanes on each live ray in turn: 16 lanes per group, 4 groups per step; the group
 // boxes are tested one group per lane.  Same exact tests, same (t, original index) merge as scan_pairs.  WAVE-LEVEL.
@@ -837,7 +837,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 
 // One iteration of color()'s bounce loop for every lane of the wave that has a ray (`has_ray`).  WAVE-LEVEL: all 64
 // lanes must call it together.  With many live lanes each lane scans the sphere list for its own ray; with few
-// (the tail of a tile / of the frame, where a handful of glass-trapped pixels need thousands of rays each) the
+// (the tail of a tile / of the frame, where a handful of pixels in sphere / ground wedges need thousands of rays each) the
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY, bool STATS = false>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
@@ -1315,8 +1315,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 uint32_t p;
                 if (CLS == 0) {
                     // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
-                    // neighbouring pixels over different waves, so the few very long pixels (paths trapped inside
-                    // glass for 50 bounces, clustered on sphere rims) never share a wave; stride 1 = tile-major order
+                    // neighbouring pixels over different waves, so the few very long pixels (50-bounce paths in the wedge between a sphere and
+                    // the ground, clustered along the contact line) never share a wave; stride 1 = tile-major order
                     p = (uint32_t)(((unsigned long long)pos * stride) % padded);
                 } else {
                     // the n0 pixels of the heavy lists are spread evenly over the first `spread` queue positions (= the lanes in
@@ -1399,8 +1399,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         }
 
         // ---- one ray per live lane, then `boost` extra rays for the lanes on a long chain ---------------------------------
-        // A pixel that keeps needing >= 10 rays per sample is one of the strictly sequential chains (paths trapped in
-        // glass) that decide when the frame ends.  While the wave is busy with 64 rays such a lane would advance one ray
+        // A pixel that keeps needing >= 10 rays per sample is one of the strictly sequential chains (paths caught in
+        // a sphere / ground wedge) that decide when the frame ends.  While the wave is busy with 64 rays such a lane would advance one ray
         // per full iteration; it gets `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
         // (One call site for both: the scan is large and must not be inlined twice.)
@@ -1613,7 +1613,9 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     int cfg = cull | (boost << 8) | (sparse_max << 16);
     static const bool chain_single = getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '1';     // experiments
     static const bool single_ray = !(getenv("RT_SINGLE_RAY") && getenv("RT_SINGLE_RAY")[0] == '0');          // scan_single for waves with one live ray
-    static const int pool_env = getenv("RT_POOL") ? atoi(getenv("RT_POOL")) : 0;                             // experiments: pooled grabs of phase 2
+    // phase 2: a normal wave reserves at least 8 queue positions per grab (one atomic round trip per ~6 finished pixels instead of per ~1: +1.3 % on C2;
+    // 16 and more hoard pixels at the end of the frame and lose: 8 -> 7144, 16 -> 6616, 32 -> 6019 Msamples/s, profiles/r03_sweep_pool.txt)
+    static const int pool_env = getenv("RT_POOL") ? atoi(getenv("RT_POOL")) : 8;
     if (chain_single) cfg |= 2;
     if (single_ray) cfg |= 4;
     cfg |= ((pool_env / 4) & 0x1F) << 3;
