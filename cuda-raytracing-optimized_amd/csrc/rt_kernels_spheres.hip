@@ -68,6 +68,22 @@ __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     return (stripe * pt.world + pt.rank) * pt.stripe_rows + (lr - stripe * pt.stripe_rows);
 }
 
+// All-ones (a NaN in every float) into the rows of the HOST framebuffer this partition member owns (P.fb with fb_global_rows: the whole image;
+// the member's local row lr is global row global_row(lr)).  Called by every thread of a grid with its flat index `tid` of `nthreads`: a pixel the work
+// distribution loses then shows as NaN instead of as the previous frame's value.  The frame's first dispatch does this beside its compute (it stores no
+// pixel: 12 bus writes of 4 bytes per thread on the benchmark frame); a single-dispatch frame runs k_poison_fb in front of its kernel.
+__device__ __forceinline__ void poison_rows(const RtSphereParams& P, size_t tid, size_t nthreads) {
+    uint32_t* fbw = reinterpret_cast<uint32_t*>(P.fb);
+    const size_t row_words = (size_t)P.nx * 3, total = (size_t)P.part.local_rows * row_words;
+    for (size_t k = tid; k < total; k += nthreads) {
+        const int lr = (int)(k / row_words);
+        fbw[(size_t)global_row(P.part, lr) * row_words + (k - (size_t)lr * row_words)] = 0xFFFFFFFFu;
+    }
+}
+__global__ void __launch_bounds__(256) k_poison_fb(const RtSphereParams P) {
+    poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
 // sphereHit, intersections.h:85-104, on a pre-normalised direction `dn` with a = dot(dn,dn) hoisted (same bits every
 // call) and r2 = radius*radius precomputed (same bits).  `t_max` is INCLUSIVE here: the caller applies the reference's
 // strict `t < closest` itself, extended by the first-index-wins tie rule (see accept()).
@@ -1134,6 +1150,7 @@ template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
+    if (PHASE == 1 && P.poison_fb) poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
     const SceneLds S = stage_scene<false, SCENE>(P, smem, &unused);
 
     const bool cull = (cfg & 1) != 0;
@@ -1526,19 +1543,23 @@ static hipError_t launch_queue_kernel(const RtSphereParams& q, unsigned blocks, 
                   : launch_queue_kernel_scene<PHASE, CLS, CHUNKED, 0>(q, blocks, lds, stream, stride, cfg, chain_cfg, caps);
 }
 
-static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
+static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream);
 
-hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready) {
+hipError_t RT_LAUNCH_NAME(const RtSphereParams& p, int variant, hipStream_t stream) {
     // p.self: the device copy of the parameter block, owned and refreshed by the renderer (one per device state and frame).  Only fields that are
     // the same for the whole frame of that device state (camera, image size, RNG mode) are read through it.  (Reading the per-pixel fields -
     // framebuffer, parked state, partition - this way too took the kernel from 61 to 43 spilled SGPRs and gained nothing more: 7030 against 7025 Msamples/s.)
     if (!p.self) return hipErrorInvalidValue;
-    return launch_spheres(p, variant, stream, fb_ready);
+    return launch_spheres(p, variant, stream);
 }
 
-static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready) {
-    // every dispatch below that stores pixels into p.fb comes after this wait; the two-dispatch frame waits later (its first dispatch only parks pixel states)
-    auto wait_fb = [&]() -> hipError_t { return fb_ready ? hipStreamWaitEvent(stream, fb_ready, 0) : hipSuccess; };
+static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream_t stream) {
+    // p.poison_fb: a single-dispatch frame is preceded by k_poison_fb on the same stream; the two-dispatch frame lets its first dispatch do it
+    auto wait_fb = [&]() -> hipError_t {
+        if (!p.poison_fb) return hipSuccess;
+        hipLaunchKernelGGL(k_poison_fb, dim3(512), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    };
     int kind = variant & 0xFF;
     const int cb_bits = (variant >> 16) & 0xFF;
     const bool legacy = cb_bits != 0 && cb_bits != 255;
@@ -1666,8 +1687,6 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         q.phase = 2;
-        e = wait_fb();
-        if (e != hipSuccess) return e;
         return launch_queue_kernel<2, 2, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg, caps);
     }
     bool classified = false;

@@ -77,6 +77,8 @@ struct RtSphereParams {
     int32_t phase;              // 0 = single launch; 1 = first samples [0, s_split) -> per-pixel state; 2 = resume [s_split, ns)
     int32_t s_split;            // samples rendered by phase 1
     int32_t chain_top_thr;      // 16 x rays per sample from which a pixel goes to chain list 0 (the longest chains; see kChainClasses)
+    int32_t poison_fb;          // 1 = `fb` is the host framebuffer (fb_global_rows) and this frame must start from NaN in the rows of this partition member: the
+                                // frame's first dispatch (which stores no pixel) fills them, or a small kernel in front of a single dispatch (poison_rows)
     float4* px_state;           // local_rows * nx: (col.xyz, rng bits) after phase 1
     uint32_t* px_rays;          // local_rows * nx: rays traced by phase 1
 };
@@ -122,9 +124,8 @@ struct RtMeshParams {
 size_t rt_sphere_kernel_lds_bytes(int n_padded, int n);
 
 // Each returns the hipError_t of the launch.  `variant` selects a kernel variant (0 = default).
-// Sphere launchers: p.self must point to a device copy of `p` that is complete on `stream` before the launch (the renderer owns it);
-// `fb_ready` (may be null): the first dispatch that stores pixels into p.fb waits for this event (the framebuffer poison of the renderer).
-hipError_t rt_launch_spheres_parity(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
-hipError_t rt_launch_spheres_fast(const RtSphereParams& p, int variant, hipStream_t stream, hipEvent_t fb_ready);
+// Sphere launchers: p.self must point to a device copy of `p` that is complete on `stream` before the launch (the renderer owns it).
+hipError_t rt_launch_spheres_parity(const RtSphereParams& p, int variant, hipStream_t stream);
+hipError_t rt_launch_spheres_fast(const RtSphereParams& p, int variant, hipStream_t stream);
 hipError_t rt_launch_mesh_parity(const RtMeshParams& p, int variant, hipStream_t stream);
 hipError_t rt_launch_mesh_fast(const RtMeshParams& p, int variant, hipStream_t stream);

@@ -47,8 +47,7 @@ void hip_check(hipError_t result, const char* func, const char* file, int line) 
 struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux = nullptr;          // second stream: the framebuffer poison runs beside the first dispatch of a frame
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fb_ready = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     RtSphereParams* d_params = nullptr; // device copy of the sphere kernel's parameter block (RtSphereParams::self), one per DeviceState
     RtSphereParams* h_params = nullptr; // its pinned staging copy (the source of the asynchronous upload must outlive the call)
     // sphere scene
@@ -123,16 +122,6 @@ struct RenderContext {
 
 RenderContext g_ctx;     // kernels.cu:145: one global context per process
 
-// All-ones (a NaN in every float) over `count` chunks of `chunk_words` dwords that lie `pitch_words` apart: the rows of the pinned HOST framebuffer
-// this partition member owns, written over the bus by the device (a host memset of the same rows would cost a millisecond per 11.5 MB frame
-// inside runRenderer; this runs on a second stream beside the frame's first dispatch, which does not touch the framebuffer).
-__global__ void __launch_bounds__(256) k_poison_rows(uint32_t* base, size_t chunk_words, size_t pitch_words, int count) {
-    for (int c = blockIdx.y; c < count; c += gridDim.y) {
-        uint32_t* row = base + (size_t)c * pitch_words;
-        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunk_words; k += (size_t)gridDim.x * blockDim.x) row[k] = 0xFFFFFFFFu;
-    }
-}
-
 void default_options(rt_render_options* o, int spheres) {
     memset(o, 0, sizeof *o);
     o->sky = spheres ? RT_SKY_GRADIENT : RT_SKY_CONST_GREY;     // kernels.cu:419-424
@@ -163,11 +152,8 @@ void free_device(DeviceState& d) {
     fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays);
     fr(d.d_params);
     if (d.h_params) HIP_CHECK(hipHostFree(d.h_params));
-    if (d.aux) HIP_CHECK(hipStreamSynchronize(d.aux));
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
     if (d.ev_stop) HIP_CHECK(hipEventDestroy(d.ev_stop));
-    if (d.ev_fb_ready) HIP_CHECK(hipEventDestroy(d.ev_fb_ready));
-    if (d.aux) HIP_CHECK(hipStreamDestroy(d.aux));
     if (d.stream) HIP_CHECK(hipStreamDestroy(d.stream));
     d = DeviceState();
 }
@@ -206,10 +192,8 @@ void setup_devices() {
         if (d.device < 0 || d.device >= count) rt_fail("device index out of range");
         HIP_CHECK(hipSetDevice(d.device));
         HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&d.ev_start));
         HIP_CHECK(hipEventCreate(&d.ev_stop));
-        HIP_CHECK(hipEventCreateWithFlags(&d.ev_fb_ready, hipEventDisableTiming));
         if (c.is_spheres) {
             HIP_CHECK(hipMalloc((void**)&d.d_params, sizeof(RtSphereParams)));
             HIP_CHECK(hipHostMalloc((void**)&d.h_params, sizeof(RtSphereParams), hipHostMallocDefault));
@@ -622,27 +606,10 @@ void runRenderer(int ns, int tx, int ty) {
         rt_vec3* const h_target = c.h_ext ? c.h_ext : c.h_fb;
         // Poison the framebuffer the kernel WRITES (all-ones = NaN): every pixel is written exactly once per frame, so a pixel the work
         // distribution lost shows up as NaN instead of as last frame's (correct-looking) value.  The compact device buffer is filled on the
-        // render stream before the timed window; the host framebuffer (direct delivery) is filled by the device on the second stream, and the
-        // launcher makes the first dispatch that stores pixels wait for it (the frame's first dispatch only parks pixel states).
-        hipEvent_t fb_ready = nullptr;
-        if (fb_direct) {
-            void* dp = nullptr;
-            HIP_CHECK(hipHostGetDevicePointer(&dp, (void*)h_target, 0));
-            const size_t stripe_words = (size_t)c.opt.stripe_rows * c.nx * 3;
-            const size_t full = d.fb_rows / (size_t)c.opt.stripe_rows, rem = d.fb_rows % (size_t)c.opt.stripe_rows;
-            uint32_t* base = reinterpret_cast<uint32_t*>(dp) + (size_t)part.rank * stripe_words;
-            if (full > 0)
-                hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)std::min<size_t>((stripe_words + 255) / 256, 64), (unsigned)std::min<size_t>(full, 1024)), dim3(256), 0, d.aux,
-                                   base, stripe_words, (size_t)world * stripe_words, (int)full);
-            if (rem > 0)
-                hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)std::min<size_t>((rem * c.nx * 3 + 255) / 256, 64), 1), dim3(256), 0, d.aux,
-                                   base + full * (size_t)world * stripe_words, rem * (size_t)c.nx * 3, (size_t)0, 1);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipEventRecord(d.ev_fb_ready, d.aux));
-            fb_ready = d.ev_fb_ready;
-        } else if (d.fb_rows > 0) {
-            HIP_CHECK(hipMemsetAsync(d.d_fb, 0xFF, d.fb_rows * row_bytes, d.stream));
-        }
+        // render stream before the timed window; with direct delivery the HOST framebuffer's rows of this partition member are filled by the
+        // device itself (RtSphereParams::poison_fb): by the frame's first dispatch, which stores no pixel (the bus writes ride beside its
+        // compute: nothing in the frame), or by a small kernel in front of a single dispatch.
+        if (!fb_direct && d.fb_rows > 0) HIP_CHECK(hipMemsetAsync(d.d_fb, 0xFF, d.fb_rows * row_bytes, d.stream));
         HIP_CHECK(hipEventRecord(d.ev_start, d.stream));
         if (c.max_depth <= 0) {
             HIP_CHECK(hipMemsetAsync(d.d_fb, 0, d.fb_rows * row_bytes, d.stream));     // loop of kernels.cu:402 never runs
@@ -689,14 +656,15 @@ void runRenderer(int ns, int tx, int ty) {
                 HIP_CHECK(hipHostGetDevicePointer(&dp, (void*)h_target, 0));
                 p.fb = reinterpret_cast<rt_vec3*>(dp);
                 p.fb_global_rows = 1;
+                p.poison_fb = 1;
             }
             // the device copy of the parameter block (RtSphereParams::self): owned by this DeviceState, refreshed by every frame from a pinned
             // staging copy (runRenderer is synchronous: the previous frame's upload has completed)
             p.self = d.d_params;
             *d.h_params = p;
             HIP_CHECK(hipMemcpyAsync(d.d_params, d.h_params, sizeof(RtSphereParams), hipMemcpyHostToDevice, d.stream));
-            HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream, fb_ready)
-                                             : rt_launch_spheres_parity(p, c.opt.variant, d.stream, fb_ready));
+            HIP_CHECK(c.opt.fp == RT_FP_FAST ? rt_launch_spheres_fast(p, c.opt.variant, d.stream)
+                                             : rt_launch_spheres_parity(p, c.opt.variant, d.stream));
             launches++;
         } else {
             RtMeshParams p;
