@@ -410,14 +410,30 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                 float mparam = 0.0f;
                 if (t < FLT_MAX) {
                     obj = 1;
-                    const Tri tri = load_tri(P.tris, J.triId);       // kernels.cu:334
-                    normal = unit(cross(tri.v1 - tri.v0, tri.v2 - tri.v0));
-                    const float w0 = 1 - J.hu - J.hv;
-                    const float tcu = (J.hu * tri.tc[2] + J.hv * tri.tc[4] + w0 * tri.tc[0]);
-                    const float tcv = (J.hu * tri.tc[3] + J.hv * tri.tc[5] + w0 * tri.tc[1]);
-                    const rt_material mat = P.materials[tri.meshID]; // kernels.cu:452-480
+                    // kernels.cu:334 re-loads the triangle.  With compact leaf records the normal and the material come from the record the leaf test read
+                    // (the two edges ARE v1 - v0 and v2 - v0 as kernels.cu:336 computes them; meshID rides in the record): the caller's 64-byte array is
+                    // touched only for the texture coordinates of a TEXTURED material - the traversal's working set (1.5 MB of node records + 1.7 MB of
+                    // records) then fits one XCD's L2.
+                    f3 e1, e2;
+                    int mesh_id;
+                    if (pair_per > 0) {
+                        const float4* rec = P.leaf_tri + (size_t)J.triId * 3;
+                        const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                        e1 = F3(ra.w, rb.x, rb.y); e2 = F3(rb.z, rb.w, rc.x);
+                        mesh_id = (int)(__float_as_uint(rc.y) & 0xFFu);
+                    } else {
+                        const Tri tri = load_tri(P.tris, J.triId);
+                        e1 = tri.v1 - tri.v0; e2 = tri.v2 - tri.v0;
+                        mesh_id = tri.meshID;
+                    }
+                    normal = unit(cross(e1, e2));
+                    const rt_material mat = P.materials[mesh_id];    // kernels.cu:452-480
                     mtype = mat.type; mparam = mat.param;
                     if (mat.texId != -1) {
+                        const float* tc = P.tris[J.triId].texCoords;
+                        const float w0 = 1 - J.hu - J.hv;
+                        const float tcu = (J.hu * tc[2] + J.hv * tc[4] + w0 * tc[0]);
+                        const float tcv = (J.hu * tc[3] + J.hv * tc[5] + w0 * tc[1]);
                         const int width = P.tex_width[mat.texId];
                         const int height = P.tex_height[mat.texId];
                         float tu = tcu; tu = tu - floorf(tu);

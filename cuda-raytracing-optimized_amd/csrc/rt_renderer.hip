@@ -517,7 +517,10 @@ void initRenderer(const rt_kernel_scene sc, const rt_camera cam, rt_vec3** fb, i
                 float4* rec = c.h_leaf_tri.data() + ((size_t)leaf * c.nppl + k) * 3;
                 rec[0] = make_float4(t.v[0].e[0], t.v[0].e[1], t.v[0].e[2], e1[0]);
                 rec[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
-                rec[2] = make_float4(e2[2], 0.0f, 0.0f, 0.0f);
+                uint32_t mesh_bits = (uint32_t)t.meshID;
+                float mesh_f;
+                memcpy(&mesh_f, &mesh_bits, 4);
+                rec[2] = make_float4(e2[2], mesh_f, 0.0f, 0.0f);       // (.y: meshID as an integer bit pattern - a closest hit reads its record again for the normal and the material)
                 cnt++;
             }
             c.h_leaf_ofs[leaf >> 2] |= cnt << (8 * (leaf & 3));

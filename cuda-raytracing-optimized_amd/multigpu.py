@@ -70,7 +70,7 @@ class ShmComm:
     MAGIC = 0x52544D4D          # "RTMM"
     SLOT = 4096
 
-    def __init__(self, rank, world, tag=None, timeout=300.0):
+    def __init__(self, rank, world, tag=None, timeout=900.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         tag = tag if tag is not None else f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self.path = f"/dev/shm/rt_comm_{tag}.bin"
