@@ -388,7 +388,7 @@ __device__ __forceinline__ uint32_t group_needs(const RtSphereParams& P, const S
     uint32_t skip = 0;
 #pragma unroll 4
     for (int g = 0; g < ng; g++) skip = __builtin_amdgcn_alignbit(skip, __float_as_uint(box_gap(S.grp + 3 * (g0 + g), br)), 31);
-    return __brev(~skip << (32 - ng));                               // 1 <= ng <= kPassGroups (16)
+    return __brev(~skip << (32 - ng));                               // 1 <= ng <= 32
 }
 
 // Inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15
@@ -427,9 +427,8 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);
     uint32_t* w_cand = reinterpret_cast<uint32_t*>(W + kWaveScratchPairs);
-    uint32_t* w_ccnt = w_cand + kCandCap;
     const float t_min = P.t_min;
-    if (lane == 0) *w_ccnt = 0u;                                     // published by the first fence below
+    uint32_t n_c = 0;                                                // wave-uniform: candidates in the list (a register: the list is this wave's own)
 
     // exact resolution of ONE candidate (owner ray, sphere slot) by this lane: the literal sphereHit tail, merged into the
     // owner's slot with the (t, original index) key.  t_max = FLT_MAX: a root beyond the owner's current best loses the min anyway.
@@ -444,9 +443,27 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
 
     w_ray[lane] = make_float4(org.x, org.y, org.z, a);
     w_ray[64 + lane] = make_float4(dn.x, dn.y, dn.z, 0.0f);
-    w_best[lane] = ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // publishes the ray table and the zeroed candidate counter
-    __builtin_amdgcn_wave_barrier();
+    w_best[lane] = ~0ull;                                            // (published, with the ray table, by the fence behind the first pair list: nothing reads them before)
+
+    // Appends every lane's candidates (`bits`: one bit per candidate; `entry_of` pops the next one) to the wave's list.  The positions come from
+    // ballots, level by level - level j = the lanes that have more than j candidates, a lane's j-th candidate lands at n_c + (lanes of level j below
+    // it) - and the count lives in a register: no LDS counter, no atomic (round 2 reserved positions with one returning LDS atomic per lane on ONE
+    // word: 30-40 lanes serialised on it, most of the kernel's LDS bank-conflict cycles, with the atomic's latency in front of every round).  The order of
+    // the list is irrelevant (the merge is an atomic min).  A lane with more than kLevels candidates, or a full list, resolves in place.  WAVE-LEVEL.
+    constexpr int kLevels = 3;
+    auto append = [&](uint32_t bits, auto entry_of) {
+#pragma unroll
+        for (int lvl = 0; lvl < kLevels; lvl++) {
+            const unsigned long long m = __ballot(bits != 0u);
+            if (m == 0ull) break;
+            if (bits != 0u) {
+                const uint32_t pos = n_c + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pos < (uint32_t)kCandCap) w_cand[pos] = entry_of(bits);     // (a full list leaves the candidate in `bits`)
+            }
+            n_c = min(n_c + (uint32_t)__popcll(m), (uint32_t)kCandCap);
+        }
+        while (bits != 0u) resolve(entry_of(bits));                  // more than kLevels candidates in one lane, or the list is full (never seen on C2): in place
+    };
 
     // 1. big spheres (ground, unit spheres; there are only a few): every lane runs phase 1 for its own ray.  The exact
     //    sphereHit tail (IEEE sqrt + divide, taken by an uneven half of the lanes) goes through the candidate list like any
@@ -455,12 +472,12 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     //    trusted to lie above t_min if it does so by that margin - so bound >= the exact closest hit of the reference
     //    (near root accepted: closest <= t1 <= bound; near root at or below t_min: the far root bounds whatever is accepted).
     float bound = FLT_MAX;
-    if (has_ray) {
-        groups_done += (uint32_t)P.n_big_groups * 4u;               // in units of 4 sphere tests
-        const float ra = __builtin_amdgcn_rcpf(a);
-        for (int k0 = 0; k0 < P.n_big; k0 += 32) {
-            uint32_t bm = 0;
-            const int kn = min(32, P.n_big - k0);
+    if (has_ray) groups_done += (uint32_t)P.n_big_groups * 4u;      // in units of 4 sphere tests
+    const float ra = __builtin_amdgcn_rcpf(a);
+    for (int k0 = 0; k0 < P.n_big; k0 += 32) {
+        uint32_t bm = 0;
+        const int kn = min(32, P.n_big - k0);
+        if (has_ray) {
 #pragma unroll 4
             for (int k = 0; k < kn; k++) {
                 const float4 sph = S.sph[sidx(k0 + k)];              // wave-uniform address: LDS broadcast
@@ -480,18 +497,12 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 if (cand) bound = fminf(bound, tb);
                 bm |= (cand ? 1u : 0u) << k;
             }
-            const uint32_t nc = (uint32_t)__popc(bm);
-            if (nc) {
-                uint32_t at = atomicAdd(w_ccnt, nc);
-                while (bm) {
-                    const int k = __builtin_ctz(bm);
-                    bm &= bm - 1u;
-                    const uint32_t e = ((uint32_t)lane << 24) | (uint32_t)(k0 + k);
-                    if (at < (uint32_t)kCandCap) w_cand[at] = e; else resolve(e);
-                    at++;
-                }
-            }
         }
+        append(bm, [&](uint32_t& bits) {
+            const int k = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            return ((uint32_t)lane << 24) | (uint32_t)(k0 + k);
+        });
     }
     lap(1);
     const BoxRay br = make_box_ray(P, org, dn, bound);
@@ -501,23 +512,34 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     // ray batch instead of once per pass.  List entries hold the ABSOLUTE group index (8 bits) and the owner lane.
     int carry = 0;                                                   // wave-uniform: pairs already in the list
     int win_base = P.n_big_groups;                                   // entries hold lane << 10 | (group - win_base): a window of 1024 groups
-    for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += kPassGroups) {
-        const int ng = min(kPassGroups, P.n_groups - g0);
+    // A scene of up to 32 small groups (the benchmark: 31) takes ONE pass of 32: one prefix sum, one list write, one synchronisation per ray batch instead of
+    // two.  The list holds 64 x 16 + 64 entries; a pass of 32 whose pairs would not fit (every ray reaching more than half of the scene: not seen) is
+    // split into its two halves of 16 groups (wave-uniform), like the passes of larger scenes.
+    const int pass_w = (P.n_groups - P.n_big_groups <= 32) ? 32 : kPassGroups;
+    for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += pass_w) {
+        const int ng = min(pass_w, P.n_groups - g0);
         // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
-        const bool flush = g0 + 2 * kPassGroups - win_base > 1024;
-        const bool last_pass = g0 + kPassGroups >= P.n_groups || flush;
-        const uint32_t need = has_ray ? group_needs(P, S, g0, ng, br, cull) : 0u;
+        const bool flush = g0 + 2 * pass_w - win_base > 1024;
+        const bool last_pass = g0 + pass_w >= P.n_groups || flush;
+        const uint32_t need_all = has_ray ? group_needs(P, S, g0, ng, br, cull) : 0u;
         if (has_ray) boxes_done += (uint32_t)ng;
         // exclusive prefix sum of the pair counts over the wave
-        const int cnt = __popc(need);
-        const int incl = wave_inclusive_scan(cnt);
+        const int cnt_all = __popc(need_all);
+        const int incl_all = wave_inclusive_scan(cnt_all);
+        const bool split = carry + __builtin_amdgcn_readlane(incl_all, 63) > kListCap;       // (pass_w = 32 only)
+      for (int half = 0; half < (split ? 2 : 1); half++) {
+        const uint32_t need = split ? (half ? need_all >> 16 : (need_all & 0xFFFFu)) : need_all;
+        const int sg0 = g0 + (split ? 16 * half : 0);
+        const bool last_sub = last_pass && (!split || half == 1);
+        const int cnt = split ? __popc(need) : cnt_all;
+        const int incl = split ? wave_inclusive_scan(cnt) : incl_all;
         const int total = carry + __builtin_amdgcn_readlane(incl, 63);
         int at = carry + incl - cnt;
-        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 10) | (g0 - win_base + __builtin_ctz(m)));
+        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 10) | (sg0 - win_base + __builtin_ctz(m)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        const int stop = last_pass ? total : (total & ~63);          // full rounds only, except in the last pass
+        const int stop = last_sub ? total : (total & ~63);           // full rounds only, except in the last pass
         lap(2);
         for (int base = 0; base < stop; base += 64) {
             // A round takes 64 pairs, one per lane, 16 sphere tests each.  The LAST round of a ray batch is partial (a batch has ~68 pairs:
@@ -527,10 +549,12 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             const int ls = left > 32 ? 0 : (left > 16 ? 1 : 2);
             const int spl = kSphereGroup >> ls;                      // sphere tests per lane
             const int j = base + (lane >> ls);
+            uint32_t mask = 0;                                       // this lane's candidates: bit 31 - k = slot0 + k
+            int owner = 0, slot0 = 0;
             if (j < stop) {
                 const unsigned pr = w_pair[j];
-                const int owner = (int)(pr >> 10);
-                const int slot0 = ((win_base + (int)(pr & 0x3FFu)) << kSphereGroupShift) + (lane & ((1 << ls) - 1)) * spl;
+                owner = (int)(pr >> 10);
+                slot0 = ((win_base + (int)(pr & 0x3FFu)) << kSphereGroupShift) + (lane & ((1 << ls) - 1)) * spl;
                 const int sbase = sidx(slot0);
                 const float4 ro = w_ray[owner], rd = w_ray[64 + owner];
                 const f3 O = F3(ro.x, ro.y, ro.z), D = F3(rd.x, rd.y, rd.z);
@@ -544,7 +568,6 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                 // exact test and changes nothing (resolve() returns FLT_MAX for it).
                 const float Ak = ro.w - 3.814697265625e-6f;
                 groups_done += (uint32_t)(spl >> 2);                 // in units of 4 sphere tests
-                uint32_t mask = 0;
                 for (int k4 = 0; k4 < spl; k4 += 4) {
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
@@ -559,52 +582,47 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
                     }
                 }
                 mask <<= (32 - spl);                                 // slot0 at bit 31
-                // The spheres whose discriminant is positive (0..3 of the 16, most often 0 or 1) still need the exact
-                // sphereHit tail: IEEE sqrt + divide, 60 instructions.  Resolved in place, the wave would loop max-over-lanes
-                // times with a quarter of its lanes busy; instead every lane appends its candidates to a wave-wide LDS list
-                // and the list is resolved 64 candidates at a time, one per lane (order-free: the merge is an atomic min).
-                const uint32_t nc = (uint32_t)__popc(mask);
-                if (nc) {
-                    uint32_t at = atomicAdd(w_ccnt, nc);
-                    while (mask) {
-                        const int lz = __clz((int)mask);
-                        mask &= ~(0x80000000u >> lz);
-                        const uint32_t e = ((uint32_t)owner << 24) | (uint32_t)(slot0 + lz);
-                        if (at < (uint32_t)kCandCap) w_cand[at] = e; else resolve(e);      // list full (never seen on C2): in place
-                        at++;
-                    }
-                }
             }
+            // The spheres whose discriminant is positive (0..3 of the 16, most often 0 or 1) still need the exact
+            // sphereHit tail: IEEE sqrt + divide, 60 instructions.  Resolved in place, the wave would loop max-over-lanes
+            // times with a quarter of its lanes busy; instead every lane appends its candidates to a wave-wide LDS list
+            // and the list is resolved 64 candidates at a time, one per lane (order-free: the merge is an atomic min).
+            append(mask, [&](uint32_t& bits) {
+                const int lz = __clz((int)bits);
+                bits &= ~(0x80000000u >> lz);
+                return ((uint32_t)owner << 24) | (uint32_t)(slot0 + lz);
+            });
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             lap(3);
-            uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);             // wave-uniform
             if (n_c >= 64u) {
                 do {
                     n_c -= 64u;
                     resolve(w_cand[n_c + (uint32_t)lane]);
                 } while (n_c >= 64u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the next round's appends overwrite what was just read)
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) *w_ccnt = n_c;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             lap(4);
         }
-        // carry the remainder to the front of the list
+        // carry the remainder to the front of the list (nothing to move when no round ran - the common first pass of a 31-group scene: its ~35 pairs
+        // already sit at the front - or when nothing is left)
         carry = total - stop;
-        unsigned short moved = 0;
-        if (lane < carry) moved = w_pair[stop + lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < carry) w_pair[lane] = moved;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (flush) win_base = g0 + kPassGroups;                      // (the list is empty here)
+        if (stop > 0 && carry > 0) {
+            unsigned short moved = 0;
+            if (lane < carry) moved = w_pair[stop + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < carry) w_pair[lane] = moved;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+      }
+        if (flush) win_base = g0 + pass_w;                           // (the list is empty here)
     }
     {                                                                // the candidates left over
-        uint32_t n_c = min(*w_ccnt, (uint32_t)kCandCap);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (big-sphere candidates when no pair round ran)
+        __builtin_amdgcn_wave_barrier();
         lap(2);
         while (n_c > 0u) {                                           // (more than 64 only if no pair round ran after the big spheres)
             const uint32_t take = min(n_c, 64u);
