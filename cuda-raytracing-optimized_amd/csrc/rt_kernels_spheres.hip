@@ -1137,7 +1137,11 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
         const int cls = class_of(p);
         if (cls >= 0) {
             const uint32_t rank = s_base[cls] + atomicAdd(&s_cnt[cls], 1u);
-            P.order[s_start[cls] + (uint32_t)(((unsigned long long)rank * s_stride[cls]) % s_n[cls])] = packed;
+            const uint32_t at = s_start[cls] + (uint32_t)(((unsigned long long)rank * s_stride[cls]) % s_n[cls]);
+            const size_t px = (size_t)(packed >> 16) * P.nx + (packed & 0xFFFFu);
+            P.order[at] = packed;
+            P.ord_state[at] = P.px_state[px];                        // the parked state travels with the list entry (see RtSphereParams::ord_state)
+            P.ord_rays[at] = P.px_rays[px];
         }
     }
 }
@@ -1347,7 +1351,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 const uint32_t item = base + rank;
                 uint32_t pos = item;                                 // position in the pixel order; the chunks of a pixel are adjacent items
                 if (CHUNKED) { pos = item / (uint32_t)P.chunks; chunk = (int)(item - pos * (uint32_t)P.chunks); }
-                uint32_t p;
+                uint32_t p, opos = 0;                                // opos: position in P.order (CLS 2): where the pixel's parked state lies as well
                 if (CLS == 0) {
                     // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
                     // neighbouring pixels over different waves, so the few very long pixels (50-bounce paths in the wedge between a sphere and
@@ -1379,7 +1383,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                     for (int k = 1; k < n_cls; k++) if (q >= s_cls_pos[k]) c = k;
                     const uint32_t j = q - s_cls_pos[c];
                     if (CLS == 2) {
-                        p = P.order[s_cls_base[c] + j];              // already permuted, already (row << 16 | column): k_order_by_cost
+                        opos = s_cls_base[c] + j;
+                        p = P.order[opos];                           // already permuted, already (row << 16 | column): k_order_by_cost
                     } else {
                         const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
                         p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
@@ -1406,14 +1411,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                         pix_rays = 0;
                     } else {                                         // resume: the pixel's stream continues where phase 1 left it
                         s_end = P.ns;
-                        const size_t px = (size_t)lr * P.nx + i;
-                        const float4 st4 = P.px_state[px];
+                        const float4 st4 = P.ord_state[opos];
                         L.i = i; L.j = global_row(P.part, lr);
                         L.pixelId = (uint32_t)(L.j * P.nx + i);
                         L.rng = __float_as_uint(st4.w);
                         L.col = F3(st4.x, st4.y, st4.z);
                         L.s = P.s_split;
-                        pix_rays = P.px_rays[px];
+                        pix_rays = P.ord_rays[opos];
                         if (wdbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
                     }
                     need_sample = true;

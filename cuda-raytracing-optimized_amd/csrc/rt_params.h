@@ -81,6 +81,8 @@ struct RtSphereParams {
                                 // frame's first dispatch (which stores no pixel) fills them, or a small kernel in front of a single dispatch (poison_rows)
     float4* px_state;           // local_rows * nx: (col.xyz, rng bits) after phase 1
     uint32_t* px_rays;          // local_rows * nx: rays traced by phase 1
+    float4* ord_state;          // the same two, copied by the ordering pass into QUEUE order (index = position in `order`): a lane that fetches a pixel in phase 2
+    uint32_t* ord_rays;         // reads its list entry, state and ray count with three independent loads (by pixel they hang behind the list entry: one more round trip)
 };
 
 struct RtMeshParams {

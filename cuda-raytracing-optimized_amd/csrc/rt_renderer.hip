@@ -80,6 +80,8 @@ struct DeviceState {
     size_t partial_bytes = 0;
     float4* d_px_state = nullptr;       // two-phase rendering: per-pixel (col, rng) and rays after the first samples
     uint32_t* d_px_rays = nullptr;
+    float4* d_ord_state = nullptr;      // ... and their copies in queue order (RtSphereParams::ord_state / ord_rays)
+    uint32_t* d_ord_rays = nullptr;
 };
 
 struct RenderContext {
@@ -149,7 +151,7 @@ void free_device(DeviceState& d) {
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_bvh_axis); fr(d.d_leaf_tri); fr(d.d_leaf_ofs); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
-    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays);
+    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays); fr(d.d_ord_state); fr(d.d_ord_rays);
     fr(d.d_params);
     if (d.h_params) HIP_CHECK(hipHostFree(d.h_params));
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
@@ -229,6 +231,8 @@ void setup_devices() {
             if (c.is_spheres) {
                 HIP_CHECK(hipMalloc((void**)&d.d_px_state, d.fb_rows * c.nx * sizeof(float4)));
                 HIP_CHECK(hipMalloc((void**)&d.d_px_rays, d.fb_rows * c.nx * sizeof(uint32_t)));
+                HIP_CHECK(hipMalloc((void**)&d.d_ord_state, padded * sizeof(float4)));
+                HIP_CHECK(hipMalloc((void**)&d.d_ord_rays, padded * sizeof(uint32_t)));
             }
         }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
@@ -633,7 +637,7 @@ void runRenderer(int ns, int tx, int ty) {
             // work items: one per pixel in the reference-stream mode (a pixel's samples are one sequential RNG stream);
             // with the per-sample counter stream the samples are independent and a pixel is split into chunks
             p.spw = spw; p.chunks = chunks; p.partial = nullptr;
-            p.phase = 0; p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays;
+            p.phase = 0; p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays; p.ord_state = d.d_ord_state; p.ord_rays = d.d_ord_rays;
             static const int top_thr_env = getenv("RT_TOP_THR") ? atoi(getenv("RT_TOP_THR")) : 0;      // experiments
             p.chain_top_thr = top_thr_env > 320 ? top_thr_env : 416;                                  // 26 rays per sample
             if (chunks > 1) {
