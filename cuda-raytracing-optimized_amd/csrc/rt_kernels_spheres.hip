@@ -1651,10 +1651,15 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // chain waves: wave 0 of every workgroup (512 waves) serves the chain lists, kSparseRays pixels to a wave; lanes of
     // normal waves above 10 rays per sample are boosted.  Measured on C2 (flat basin) with the multi-ray sparse form:
     // 512 waves x 4 pixels 5780, x 3: 5740, x 2: 5720; 1024 waves x 2: 5610 Msamples/s (before it: 256 x 4: 5040, 512 x 2: 5540).
-    int chain_cfg = 1 | ((waves / 8) << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
-    int caps = 4 | (4 << 4) | (4 << 8) | (4 << 12);     // pixels a chain wave holds while one of them comes from chain list 0 / 1 / 2 / 3
+    // chain waves: three of the 16 waves of every workgroup (768) serve the chain lists.  They take ONE pixel per grab (the grabs of the waves interleave: the
+    // head of the lists - the longest estimates - is dealt one pixel to a wave), a wave that holds a pixel of list 0 (>= 24 rays per sample estimated: ~250 pixels,
+    // among them every pixel above 3000 rays) holds nothing else and traces it in the single-ray form, the others hold up to kSparseRays.  Round 3, after
+    // the dense iteration had gained 4 %: 7300 against 7117 Msamples/s with 512 waves x 4 pixels (profiles/r03_sweep_tail5.txt, r03_sweep_tail6.txt; a flat
+    // basin: 768 waves, list 0 from 20..26 rays per sample, 2..4 pixels for the other lists all within 0.5 %; 1024 waves -2 %, list 0 from 30: -6 %).
+    int chain_cfg = 1 | ((waves == 16 ? 3 : 1) << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
+    int caps = 1 | (4 << 4) | (4 << 8) | (4 << 12);     // pixels a chain wave holds while one of them comes from chain list 0 / 1 / 2 / 3
     int cfg = cull | (boost << 8) | (sparse_max << 16);
-    static const bool chain_single = getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '1';     // experiments
+    static const bool chain_single = !(getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '0');  // chain waves grab one pixel at a time
     static const bool single_ray = !(getenv("RT_SINGLE_RAY") && getenv("RT_SINGLE_RAY")[0] == '0');          // scan_single for waves with one live ray
     // phase 2: a normal wave reserves at least 8 queue positions per grab (one atomic round trip per ~6 finished pixels instead of per ~1: +1.3 % on C2;
     // 16 and more hoard pixels at the end of the frame and lose: 8 -> 7144, 16 -> 6616, 32 -> 6019 Msamples/s, profiles/r03_sweep_pool.txt)
@@ -1665,7 +1670,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     static const bool dbg_light = getenv("RT_WAVE_DEBUG_LIGHT") && getenv("RT_WAVE_DEBUG_LIGHT")[0] == '1';
     if (dbg_light) cfg |= 1 << 29;
     if (const char* t = getenv("RT_TUNE")) {        // experiments: "chain_every,chain_waves,heavy_thr,n_chain,boost,chain_pixels,chain_pixels of list 0,1,2"
-        int a = 1, b = waves / 8, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 4, g1 = 4, g2 = 4;
+        int a = 1, b = waves == 16 ? 3 : 1, c = 8, d = kChainClasses, e2 = boost, f = kSparseRays, g = 1, g1 = 4, g2 = 4;
         sscanf(t, "%d,%d,%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e2, &f, &g, &g1, &g2);
         // every field is a bit-field of chain_cfg / cfg and some are divisors or loop bounds in the kernel: refuse what does not fit
         if (a < 1 || a > 255 || b < 0 || b > waves || c < 1 || c > 255 || d < 0 || d > 15 || e2 < 0 || e2 > 255 ||

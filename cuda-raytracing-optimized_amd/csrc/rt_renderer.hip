@@ -639,7 +639,7 @@ void runRenderer(int ns, int tx, int ty) {
             p.spw = spw; p.chunks = chunks; p.partial = nullptr;
             p.phase = 0; p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays; p.ord_state = d.d_ord_state; p.ord_rays = d.d_ord_rays;
             static const int top_thr_env = getenv("RT_TOP_THR") ? atoi(getenv("RT_TOP_THR")) : 0;      // experiments
-            p.chain_top_thr = top_thr_env > 320 ? top_thr_env : 416;                                  // 26 rays per sample
+            p.chain_top_thr = top_thr_env >= 320 ? top_thr_env : 384;                                 // 24 rays per sample
             if (chunks > 1) {
                 const size_t need = d.fb_rows * c.nx * (size_t)p.chunks * sizeof(rt_vec3);
                 if (need > d.partial_bytes) {
