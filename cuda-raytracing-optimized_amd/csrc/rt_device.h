@@ -23,6 +23,9 @@ __device__ __forceinline__ void rt_sincosf(float y, float& s, float& c) {
     if (!rt_glibc_sincosf(y, &s, &c)) sincosf(y, &s, &c);
 }
 __device__ __forceinline__ float rt_sinf(float y) { float s, c; rt_sincosf(y, s, c); return s; }
+// checker_layer's sin x * sin y * sin z (material.h:33-36): a dormant look preset.  A real function, not inlined: three inlined copies of the fp64
+// polynomial inside the shading code cost every kernel two VGPRs for a hoisted constant and a spill, whether a scene uses the preset or not.
+__device__ __attribute__((noinline)) float rt_checker_sines(float x, float y, float z) { return rt_sinf(x) * rt_sinf(y) * rt_sinf(z); }
 
 struct f3 { float x, y, z; };
 
@@ -184,7 +187,7 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
     case RT_FLOOR_COAT:    bsdf = B_COAT; ior = 1.5f; albedo = hex_color(0x511845); tint = F3(1, 1, 1); break;
     case RT_FLOOR_DIFFUSE: bsdf = B_DIFFUSE; albedo = hex_color(0x511845); break;
     case RT_FLOOR_CHECKER: {                                                     // checker_layer, material.h:33-36
-        const float sines = rt_sinf(0.2f * hp.x) * rt_sinf(0.2f * hp.y) * rt_sinf(0.2f * hp.z);
+        const float sines = rt_checker_sines(0.2f * hp.x, 0.2f * hp.y, 0.2f * hp.z);
         bsdf = B_DIFFUSE; albedo = (sines < 0) ? hex_color(0x511845) : hex_color(0xff5733);
         break;
     }

@@ -138,16 +138,16 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
     if (SCENE == 2) {
-        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups);
+        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups + kCellTableWords / 4);
         for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += (int)blockDim.x) s_sph[k] = P.spheres[k];
         for (int k = threadIdx.x; k < P.n_padded; k += (int)blockDim.x) s_org[k] = P.orig[k];
-        for (int k = threadIdx.x; k < 3 * P.n_groups; k += (int)blockDim.x) s_grp[k] = P.groups[k];
+        for (int k = threadIdx.x; k < 3 * P.n_groups + kCellTableWords / 4; k += (int)blockDim.x) s_grp[k] = P.groups[k];     // (boxes + their cell tables)
         *after = nullptr;
         unsigned char* scratch = reinterpret_cast<unsigned char*>(s_org + P.n_padded);
         __syncthreads();
         return { s_sph, s_grp, P.mat_color, P.mat_type, s_org, P.slot_of, P.rad, scratch };
     }
-    float4* s_mat = s_grp + 3 * P.n_groups;
+    float4* s_mat = s_grp + 3 * P.n_groups + kCellTableWords / 4;
     int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
     int*    s_org = s_typ + P.n_padded;
     float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
@@ -159,7 +159,7 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
     }
-    for (int k = threadIdx.x; k < 3 * P.n_groups; k += (int)blockDim.x) s_grp[k] = P.groups[k];
+    for (int k = threadIdx.x; k < 3 * P.n_groups + kCellTableWords / 4; k += (int)blockDim.x) s_grp[k] = P.groups[k];
     for (int k = threadIdx.x; k < P.n; k += (int)blockDim.x) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
     *after = s_fb;                                                   // WITH_FB (tile kernel): kThreads x 3 floats of framebuffer staging
@@ -311,7 +311,7 @@ __device__ __forceinline__ Hit scan_cooperative(const RtSphereParams& P, const S
 // (lo * inv - (org + m) * inv: six v_fma_f32 per box instead of twelve sub / mul).
 // The two planes of an axis are not ordered by min / max after the fact: the box stores (lo, hi, lo) per axis and the ray reads two consecutive
 // floats at offset 0 (direction >= 0: near = lo, far = hi) or 1 (near = hi, far = lo) - six VALU instructions fewer per box.
-struct BoxRay { f3 inv, cn, cf; float cb; uint32_t sx, sy, sz; };   // cn / cf: (org +- m) * inv of the near / far plane; s*: 0 or 1
+struct BoxRay { f3 inv, cn, cf; float cb, m; uint32_t sx, sy, sz; };   // cn / cf: (org +- m) * inv of the near / far plane; m: the margin; s*: 0 or 1
 
 __device__ __forceinline__ BoxRay make_box_ray(const RtSphereParams& P, f3 org, f3 dn, float closest) {
     BoxRay r;
@@ -326,6 +326,7 @@ __device__ __forceinline__ BoxRay make_box_ray(const RtSphereParams& P, f3 org, 
     r.cn = F3(r.sx ? chi.x : clo.x, r.sy ? chi.y : clo.y, r.sz ? chi.z : clo.z);
     r.cf = F3(r.sx ? clo.x : chi.x, r.sy ? clo.y : chi.y, r.sz ? clo.z : chi.z);
     r.cb = (closest + 1.0e-4f) * 1.00002f;
+    r.m = m;
     return r;
 }
 
@@ -376,6 +377,61 @@ __device__ __forceinline__ uint32_t group_needs_shared(const SceneLds& S, int g0
     }
     for (; g < ng; g++) skip = __builtin_amdgcn_alignbit(skip, gap(*reinterpret_cast<const f2u*>(f1 + 12 * g), *reinterpret_cast<const f2u*>(f2 + 12 * g)), 31);
     return __brev(~skip << (32 - ng));
+}
+
+// The same test behind a PREFILTER (scenes of <= 32 small groups with a shared axis, RtSphereParams::cell_on): the part of the ray inside the shared
+// slab - t in [in0, out0], already clipped to [0, closest hit] - has a bounding rectangle on the two other axes, and the host's cell tables give, per cell,
+// the boxes that begin at or below it and those that end at or above it: four LDS words and three ANDs leave the boxes whose rectangle overlaps the
+// ray's (on the benchmark scene 2-3 of the 31), and only those take the box test, two per step of a per-lane loop.  A lane whose ray lies long in
+// the slab (grazing rays: many candidates) would hold the wave: beyond kCellLoopMax candidates in any lane the wave takes the uniform loop instead.
+// Conservative by itself: a box the ray enters at t* in [0, closest] contains the point org + t* d (up to the margin m, by which the ray's rectangle is
+// widened here as the boxes are in the test); t* lies in the computed [in0, out0] (that is the slab test's own guarantee, the shared axis being one of
+// its three), so the point's coordinates lie between the segment's end points - computed with two roundings each, covered by the 2^-20 relative pad - and
+// the cell index is off by less than one cell (the tables' slack).  An infinite or NaN end point (no hit yet and a ray parallel to the slab) clamps to
+// the first / last cell, whose words reject nothing.
+constexpr int kCellLoopMax = 12;
+template <int AX>
+__device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& r, f3 org, f3 dn,
+                                                      float shared_lo, float shared_hi, uint32_t& boxes_done, bool& uniform) {
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    constexpr int A1 = (AX + 1) % 3, A2 = (AX + 2) % 3;
+    const float* f = reinterpret_cast<const float*>(S.grp + 3 * g0);
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(S.grp + 3 * P.n_groups);
+    const float s_near = bsign<AX>(r) ? shared_hi : shared_lo, s_far = bsign<AX>(r) ? shared_lo : shared_hi;
+    const float in0 = fmaxf(__builtin_fmaf(s_near, comp<AX>(r.inv), -comp<AX>(r.cn)), 0.0f);
+    const float out0 = fminf(__builtin_fmaf(s_far, comp<AX>(r.inv), -comp<AX>(r.cf)), r.cb);
+    auto overlap = [&](float o, float d, int q) -> uint32_t {
+        const float x0 = __builtin_fmaf(in0, d, o), x1 = __builtin_fmaf(out0, d, o);
+        const float pad = r.m + 9.5367431640625e-7f * (fabsf(o) + fabsf(x0) + fabsf(x1));
+        const float lo = fminf(x0, x1) - pad, hi = fmaxf(x0, x1) + pad;
+        // (a NaN goes to the permissive end: fmaxf / fminf return their other operand)
+        const float c_lo = fminf(fmaxf(__builtin_fmaf(lo, P.cell_scale[q], P.cell_off[q]), 0.0f), (float)(kCellCount - 1));
+        const float c_hi = fmaxf(fminf(__builtin_fmaf(hi, P.cell_scale[q], P.cell_off[q]), (float)(kCellCount - 1)), 0.0f);
+        return tab[2 * kCellCount * q + (int)c_hi] & tab[2 * kCellCount * q + kCellCount + (int)c_lo];
+    };
+    uint32_t cand = overlap(comp<A1>(org), comp<A1>(dn), 0) & overlap(comp<A2>(org), comp<A2>(dn), 1);
+    if (!(in0 <= out0)) cand = 0u;                                   // the ray misses the slab (or leaves it behind its closest hit): the box test would skip every box
+    if (__builtin_amdgcn_ballot_w64(__popc(cand) > kCellLoopMax) != 0ull) { uniform = true; return 0u; }       // the caller runs the uniform loop
+    boxes_done += (uint32_t)__popc(cand);
+    const float* f1 = f + 4 * A1 + bsign<A1>(r);
+    const float* f2 = f + 4 * A2 + bsign<A2>(r);
+    auto gap = [&](f2u p1, f2u p2) {
+        const float t_in = fmaxf(fmaxf(__builtin_fmaf(p1.x, comp<A1>(r.inv), -comp<A1>(r.cn)), __builtin_fmaf(p2.x, comp<A2>(r.inv), -comp<A2>(r.cn))), in0);
+        const float t_out = fminf(fminf(__builtin_fmaf(p1.y, comp<A1>(r.inv), -comp<A1>(r.cf)), __builtin_fmaf(p2.y, comp<A2>(r.inv), -comp<A2>(r.cf))), out0);
+        return __float_as_uint(t_out - t_in);
+    };
+    uint32_t need = 0;
+    while (cand != 0u) {                                             // (per lane: the wave runs max-over-lanes / 2 steps)
+        const int ga = __builtin_ctz(cand);
+        cand &= cand - 1u;
+        const int gb = cand != 0u ? __builtin_ctz(cand) : ga;        // (a lone last candidate is tested twice: the same bit)
+        cand &= cand - 1u;
+        const f2u a1 = *reinterpret_cast<const f2u*>(f1 + 12 * ga), a2 = *reinterpret_cast<const f2u*>(f2 + 12 * ga);
+        const f2u b1 = *reinterpret_cast<const f2u*>(f1 + 12 * gb), b2 = *reinterpret_cast<const f2u*>(f2 + 12 * gb);
+        need |= ((~gap(a1, a2)) >> 31) << ga;
+        need |= ((~gap(b1, b2)) >> 31) << gb;
+    }
+    return need;
 }
 
 __device__ __forceinline__ uint32_t group_needs(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& br, bool cull) {
@@ -521,8 +577,17 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
         const bool flush = g0 + 2 * pass_w - win_base > 1024;
         const bool last_pass = g0 + pass_w >= P.n_groups || flush;
-        const uint32_t need_all = has_ray ? group_needs(P, S, g0, ng, br, cull) : 0u;
-        if (has_ray) boxes_done += (uint32_t)ng;
+        uint32_t need_all = 0u;
+        if (has_ray) {
+            bool uniform = !(cull && P.cell_on != 0);
+            if (!uniform) {                                          // (<= 32 small groups: this is the only pass, g0 = n_big_groups)
+                need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done, uniform);
+            }
+            if (uniform) {
+                need_all = group_needs(P, S, g0, ng, br, cull);
+                boxes_done += (uint32_t)ng;
+            }
+        }
         // exclusive prefix sum of the pair counts over the wave
         const int cnt_all = __popc(need_all);
         const int incl_all = wave_inclusive_scan(cnt_all);
@@ -1511,7 +1576,7 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg) {
     // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
-    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48;
+    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 + (size_t)kCellTableWords * 4;
     const size_t scratch = (size_t)waves * kWaveScratch;
     if (scene == 1) return scratch;
     if (scene == 2) return test_data + (size_t)n_padded * 4 + scratch;

@@ -101,6 +101,8 @@ struct RenderContext {
     std::vector<float4> h_groups;       // three float4 per group of kSphereGroup slots: per axis (lo, hi, lo, -) of the tight AABB
     float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0, pair_k0 = 0;
     int box_shared_axis = 0;
+    int cell_on = 0;
+    float cell_scale[2] = { 0, 0 }, cell_off[2] = { 0, 0 };
     float box_shared_lo = 0, box_shared_hi = 0;
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
@@ -397,6 +399,48 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     }
     c.box_shared_axis = 0;
     for (int a = 2; a >= 0; a--) if (n_boxes > 0 && shared_ok[a]) { c.box_shared_axis = a + 1; c.box_shared_lo = shared_lo[a]; c.box_shared_hi = shared_hi[a]; }
+    // Cell tables (rt_params.h, group_needs_cells): for scenes of <= 32 small groups whose boxes share an axis.  Bit g of a word = small group g.
+    // begins[c] = boxes with lo <= upper edge of cell c + one cell, ends[c] = boxes with hi >= lower edge of cell c - one cell (the slack of one cell
+    // covers the rounding of the device's cell index); the last begins-word and the first ends-word hold every box, so that a coordinate beyond the
+    // tables' extent - clamped to the first / last cell on the device - rejects nothing it should not.
+    c.cell_on = 0;
+    c.h_groups.resize((size_t)c.n_groups * 3 + kCellTableWords / 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    const int n_small_groups = c.n_groups - n_big_groups;
+    if (c.box_shared_axis == 2 && n_boxes > 0 && n_small_groups <= 32) {      // (the kernel instantiates the prefilter for a shared y axis only: spheres on a horizontal plane)
+        const int ax = c.box_shared_axis - 1;
+        const int axes[2] = { (ax + 1) % 3, (ax + 2) % 3 };
+        uint32_t* tab = reinterpret_cast<uint32_t*>(c.h_groups.data() + (size_t)c.n_groups * 3);
+        uint32_t all = 0;
+        for (int g = n_big_groups; g < c.n_groups; g++) if (c.h_groups[3 * g].x <= c.h_groups[3 * g].y) all |= 1u << (g - n_big_groups);
+        bool ok = true;
+        for (int q = 0; q < 2; q++) {
+            const int a = axes[q];
+            double amin = 1e300, amax = -1e300;
+            for (int g = n_big_groups; g < c.n_groups; g++) {
+                if (!((all >> (g - n_big_groups)) & 1u)) continue;
+                amin = std::min(amin, (double)c.h_groups[3 * g + a].x);
+                amax = std::max(amax, (double)c.h_groups[3 * g + a].y);
+            }
+            const double w = (amax - amin) / kCellCount;
+            if (!(w > 1e-30) || !std::isfinite(w) || !std::isfinite(1.0 / w) || !std::isfinite(amin / w)) { ok = false; break; }
+            c.cell_scale[q] = (float)(1.0 / w);
+            c.cell_off[q] = (float)(-amin / w);
+            for (int cell = 0; cell < kCellCount; cell++) {
+                uint32_t begins = 0, ends = 0;
+                for (int g = n_big_groups; g < c.n_groups; g++) {
+                    if (!((all >> (g - n_big_groups)) & 1u)) continue;
+                    if ((double)c.h_groups[3 * g + a].x <= amin + (cell + 2) * w) begins |= 1u << (g - n_big_groups);
+                    if ((double)c.h_groups[3 * g + a].y >= amin + (cell - 1) * w) ends |= 1u << (g - n_big_groups);
+                }
+                if (cell == kCellCount - 1) begins = all;
+                if (cell == 0) ends = all;
+                tab[2 * kCellCount * q + cell] = begins;
+                tab[2 * kCellCount * q + kCellCount + cell] = ends;
+            }
+        }
+        static const bool cells_off = getenv("RT_BOX_CELLS") && getenv("RT_BOX_CELLS")[0] == '0';
+        c.cell_on = (ok && !cells_off) ? 1 : 0;
+    }
     // per-ray margin constants
     double cc[3] = { 0, 0, 0 }, rad = 0.0;
     if (!small.empty()) {
@@ -629,6 +673,7 @@ void runRenderer(int ns, int tx, int ty) {
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
             p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max; p.pair_k0 = c.pair_k0; p.box_shared_axis = c.box_shared_axis; p.box_shared_lo = c.box_shared_lo; p.box_shared_hi = c.box_shared_hi;
+            p.cell_on = c.cell_on; for (int q = 0; q < 2; q++) { p.cell_scale[q] = c.cell_scale[q]; p.cell_off[q] = c.cell_off[q]; }
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;
