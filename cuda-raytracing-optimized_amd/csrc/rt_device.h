@@ -76,22 +76,33 @@ __device__ __forceinline__ float rnd(uint32_t& state) {             // rnd.h:5-1
     state = x;
     return (float)(x & 0xFFFFFF) / 16777216.0f;
 }
+// 2.0f * rnd(state) - 1.0f, the bits the two roundings of rnd.h:23,45 produce, in one: rnd is n * 2^-24 with n < 2^24 (the conversion and the scaling are
+// exact), 2.0f * that is exact as well, so the subtraction is the only rounding - RN(n * 2^-23 - 1), which is what the fused multiply-add returns.
+// (The rejection loops below run max-over-lanes times per wave: this is 6 of their 38 instructions.)
+__device__ __forceinline__ float rnd_pm1(uint32_t& state) {
+    uint32_t x = state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 15;
+    state = x;
+    return __builtin_fmaf((float)(x & 0xFFFFFF), 1.1920928955078125e-7f, -1.0f);
+}
 __device__ __forceinline__ f3 random_in_unit_disk(uint32_t& state) {    // rnd.h:20-26, draws x then y
     f3 p;
     do {
-        const float rx = rnd(state);
-        const float ry = rnd(state);
-        p = 2.0f * F3(rx, ry, 0.0f) - F3(1.0f, 1.0f, 0.0f);
+        const float px = rnd_pm1(state);
+        const float py = rnd_pm1(state);
+        p = F3(px, py, 0.0f);                                            // (2.0f * 0.0f - 0.0f)
     } while (dot(p, p) >= 1.0f);
     return p;
 }
 __device__ __forceinline__ f3 random_in_unit_sphere(uint32_t& state) {  // rnd.h:41-49, draws x,y,z
     f3 p;
     do {
-        const float rx = rnd(state);
-        const float ry = rnd(state);
-        const float rz = rnd(state);
-        p = 2.0f * F3(rx, ry, rz) - F3(1.0f, 1.0f, 1.0f);
+        const float px = rnd_pm1(state);
+        const float py = rnd_pm1(state);
+        const float pz = rnd_pm1(state);
+        p = F3(px, py, pz);
     } while (sqlen(p) >= 1.0f);
     return p;
 }

@@ -379,20 +379,21 @@ __device__ __forceinline__ uint32_t group_needs_shared(const SceneLds& S, int g0
     return __brev(~skip << (32 - ng));
 }
 
-// The same test behind a PREFILTER (scenes of <= 32 small groups with a shared axis, RtSphereParams::cell_on): the part of the ray inside the shared
+// The same test behind a PREFILTER (scenes of <= 32 small groups that share the y axis, RtSphereParams::cell_on): the part of the ray inside the shared
 // slab - t in [in0, out0], already clipped to [0, closest hit] - has a bounding rectangle on the two other axes, and the host's cell tables give, per cell,
 // the boxes that begin at or below it and those that end at or above it: four LDS words and three ANDs leave the boxes whose rectangle overlaps the
-// ray's (on the benchmark scene 2-3 of the 31), and only those take the box test, two per step of a per-lane loop.  A lane whose ray lies long in
-// the slab (grazing rays: many candidates) would hold the wave: beyond kCellLoopMax candidates in any lane the wave takes the uniform loop instead.
+// ray's (on the benchmark scene 2-3 of the 31), and only those take the box test, two per step of a per-lane loop: the wave runs as many steps as
+// its lane with the most candidates needs (a grazing ray that lies long in the slab), which measured better than falling back to the uniform loop
+// from any threshold (A/B on C5 at 256 spp, profiles/r03_ab_cells.txt: uniform loop 9765, prefilter 10280 Msamples/s; 64 cells per axis; 32: -0.2 %,
+// 128: -0.3 %; fall-back above 6 candidates -1.8 %, above 12 -0.3 %).
 // Conservative by itself: a box the ray enters at t* in [0, closest] contains the point org + t* d (up to the margin m, by which the ray's rectangle is
 // widened here as the boxes are in the test); t* lies in the computed [in0, out0] (that is the slab test's own guarantee, the shared axis being one of
 // its three), so the point's coordinates lie between the segment's end points - computed with two roundings each, covered by the 2^-20 relative pad - and
-// the cell index is off by less than one cell (the tables' slack).  An infinite or NaN end point (no hit yet and a ray parallel to the slab) clamps to
+// the cell index is off by less than the tables' slack.  An infinite or NaN end point (no hit yet and a ray parallel to the slab) clamps to
 // the first / last cell, whose words reject nothing.
-constexpr int kCellLoopMax = 12;
 template <int AX>
 __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& r, f3 org, f3 dn,
-                                                      float shared_lo, float shared_hi, uint32_t& boxes_done, bool& uniform) {
+                                                      float shared_lo, float shared_hi, uint32_t& boxes_done) {
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     constexpr int A1 = (AX + 1) % 3, A2 = (AX + 2) % 3;
     const float* f = reinterpret_cast<const float*>(S.grp + 3 * g0);
@@ -411,7 +412,6 @@ __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, c
     };
     uint32_t cand = overlap(comp<A1>(org), comp<A1>(dn), 0) & overlap(comp<A2>(org), comp<A2>(dn), 1);
     if (!(in0 <= out0)) cand = 0u;                                   // the ray misses the slab (or leaves it behind its closest hit): the box test would skip every box
-    if (__builtin_amdgcn_ballot_w64(__popc(cand) > kCellLoopMax) != 0ull) { uniform = true; return 0u; }       // the caller runs the uniform loop
     boxes_done += (uint32_t)__popc(cand);
     const float* f1 = f + 4 * A1 + bsign<A1>(r);
     const float* f2 = f + 4 * A2 + bsign<A2>(r);
@@ -579,11 +579,9 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         const bool last_pass = g0 + pass_w >= P.n_groups || flush;
         uint32_t need_all = 0u;
         if (has_ray) {
-            bool uniform = !(cull && P.cell_on != 0);
-            if (!uniform) {                                          // (<= 32 small groups: this is the only pass, g0 = n_big_groups)
-                need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done, uniform);
-            }
-            if (uniform) {
+            if (cull && P.cell_on != 0) {                            // (<= 32 small groups: this is the only pass, g0 = n_big_groups; shared axis y)
+                need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done);
+            } else {
                 need_all = group_needs(P, S, g0, ng, br, cull);
                 boxes_done += (uint32_t)ng;
             }

@@ -16,7 +16,7 @@
 // sphere tests per ray grow with the group while the box tests shrink: 16 -> 5100 Msamples/s, 32 -> 4950.
 constexpr int kSphereGroupShift = 4;
 constexpr int kSphereGroup = 1 << kSphereGroupShift;
-constexpr int kCellCount = 32;                          // cells per axis of the group boxes' cell tables (RtSphereParams::cell_on)
+constexpr int kCellCount = 64;                          // cells per axis of the group boxes' cell tables (RtSphereParams::cell_on)
 constexpr int kCellTableWords = 4 * kCellCount;         // (begins-below, ends-above) x two axes; always present behind the group boxes (zero when unused)
 
 struct RtPartition {
@@ -60,7 +60,7 @@ struct RtSphereParams {
     float pair_k0;              // 2 * kPairSlack * (largest radius of the grouped spheres)^2: see the pair rounds of scan_pairs
     // Cell tables of the group boxes (scenes of <= 32 small groups with a shared axis; see group_needs_cells): behind the 3 x n_groups box entries of `groups`
     // lie kCellTableWords words - for each of the two other axes 32 cells over the boxes' extent, and per cell the set (bit g = small group g) of the
-    // boxes that begin at or below the cell (+ one cell) and of those that end at or above it (- one cell).  cell = x * cell_scale[a] + cell_off[a].
+    // boxes that begin at or below the cell and of those that end at or above it.  cell = x * cell_scale[a] + cell_off[a].
     int32_t cell_on;
     float cell_scale[2], cell_off[2];
     const float4* mat_color;    // n_padded x (r, g, b, param)

@@ -400,9 +400,11 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     c.box_shared_axis = 0;
     for (int a = 2; a >= 0; a--) if (n_boxes > 0 && shared_ok[a]) { c.box_shared_axis = a + 1; c.box_shared_lo = shared_lo[a]; c.box_shared_hi = shared_hi[a]; }
     // Cell tables (rt_params.h, group_needs_cells): for scenes of <= 32 small groups whose boxes share an axis.  Bit g of a word = small group g.
-    // begins[c] = boxes with lo <= upper edge of cell c + one cell, ends[c] = boxes with hi >= lower edge of cell c - one cell (the slack of one cell
-    // covers the rounding of the device's cell index); the last begins-word and the first ends-word hold every box, so that a coordinate beyond the
-    // tables' extent - clamped to the first / last cell on the device - rejects nothing it should not.
+    // begins[c] = boxes with lo <= upper edge of cell c, ends[c] = boxes with hi >= lower edge of cell c, both with a slack of kCellSlack cells for
+    // the rounding of the device's cell index (x * scale + off in fp32 with |index| <= kCellCount: off by < 2e-5 cells); the last begins-word and the
+    // first ends-word hold every box, so that a coordinate beyond the tables' extent - clamped to the first / last cell on the device - rejects
+    // nothing it should not.
+    constexpr double kCellSlack = 1.0e-3;
     c.cell_on = 0;
     c.h_groups.resize((size_t)c.n_groups * 3 + kCellTableWords / 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     const int n_small_groups = c.n_groups - n_big_groups;
@@ -429,8 +431,8 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
                 uint32_t begins = 0, ends = 0;
                 for (int g = n_big_groups; g < c.n_groups; g++) {
                     if (!((all >> (g - n_big_groups)) & 1u)) continue;
-                    if ((double)c.h_groups[3 * g + a].x <= amin + (cell + 2) * w) begins |= 1u << (g - n_big_groups);
-                    if ((double)c.h_groups[3 * g + a].y >= amin + (cell - 1) * w) ends |= 1u << (g - n_big_groups);
+                    if ((double)c.h_groups[3 * g + a].x <= amin + (cell + 1 + kCellSlack) * w) begins |= 1u << (g - n_big_groups);
+                    if ((double)c.h_groups[3 * g + a].y >= amin + (cell - kCellSlack) * w) ends |= 1u << (g - n_big_groups);
                 }
                 if (cell == kCellCount - 1) begins = all;
                 if (cell == 0) ends = all;
