@@ -1671,7 +1671,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // bits 30..31: a wave switches to the sparse form at <= 4 / 8 / 12 / 16 live rays (0 = default)
     int sparse_max = 4 + 4 * ((variant >> 30) & 3);
     if (cb_bits == 255) sparse_max = 0;         // pair-compacted scan only (A/B): never the sparse form
-    const int boost = (pb == 7 || cb_bits == 255) ? 0 : (pb == 0 ? 2 : pb);      // measured on C2 (round 2): threshold 8, 2 extra rays: 6300; 10 / 4 (round 1): 6190 Msamples/s
+    const int boost = (pb == 7 || cb_bits == 255) ? 0 : (pb == 0 ? 1 : pb);      // measured on C2: round 2 threshold 8, 2 extra steps: 6300 against 6190 with 10 / 4; round 3, after the dense
+                                                                                 // iteration had gained 10 %: 1 extra step 7850, 2: 7650 Msamples/s (profiles/r03_sweep_tail9.txt)
     if (kind == 1) {
         int coop_below = cb_bits;
         if (coop_below == 0) coop_below = -1;      // pair-compacted scan (+ sparse form)
