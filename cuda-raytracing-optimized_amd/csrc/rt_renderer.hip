@@ -440,7 +440,7 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
                 tab[2 * kCellCount * q + kCellCount + cell] = ends;
             }
         }
-        static const bool cells_off = getenv("RT_BOX_CELLS") && getenv("RT_BOX_CELLS")[0] == '0';
+        const bool cells_off = getenv("RT_BOX_CELLS") && getenv("RT_BOX_CELLS")[0] == '0';     // (read at every init: the tests render with and without)
         c.cell_on = (ok && !cells_off) ? 1 : 0;
     }
     // per-ray margin constants

@@ -237,6 +237,53 @@ def test_spheres_on_a_plane_share_a_box_slab(rt, O, axis):
     assert st.rays == cnt.rays
 
 
+@pytest.mark.parametrize("view", ["level", "below", "inside", "far", "steep", "no_big"])
+def test_cell_table_prefilter_of_the_group_boxes(rt, O, view, monkeypatch):
+    """Spheres resting on a horizontal plane in <= 32 groups (the benchmark's shape): the group box tests run behind the cell-table prefilter
+    (group_needs_cells, rt_kernels_spheres.hip).  Views chosen against it: rays that run inside the slab of the small spheres, level with it
+    (the slab interval is long, or unbounded when nothing big is hit: end points at infinity), from below the plane, from inside the slab,
+    from 2000 units away (the margin m exceeds a cell), straight down, and a scene without any big sphere (no bound at all).  Bit-exact
+    against the oracle, with the prefilter and without (RT_BOX_CELLS=0), ray counts equal."""
+    rng = np.random.default_rng(4242)
+    n = 430
+    sp = np.zeros(n, rt.sphere_dtype)
+    mt = np.zeros(n, rt.material_dtype)
+    c = rng.uniform(-9, 9, (n, 3))
+    c[:, 1] = 0.2
+    sp["center"] = c
+    sp["radius"] = 0.2
+    first = 0
+    if view != "no_big":
+        sp["center"][0] = (0, -1000, 0); sp["radius"][0] = 1000
+        sp["center"][1] = (0, 1, 0); sp["radius"][1] = 1.0
+        first = 2
+    mt["type"] = rng.integers(0, 3, n)
+    mt["color"] = rng.uniform(0.1, 1, (n, 3))
+    mt["param"] = np.where(mt["type"] == rt.RT_GLASS, 1.5, rng.uniform(0, 0.3, n))
+    mt["texId"] = -1
+    assert first <= 2
+    nx, ny, ns, depth = 96, 33, 3, 12
+    cams = {
+        "level":  rt.make_camera((12, 0.2, 1), (0, 0.2, 0), (0, 1, 0), 30.0, nx / ny, 0.0, 10.0),
+        "below":  rt.make_camera((6, -3.0, 2), (0, 0.2, 0), (0, 1, 0), 50.0, nx / ny, 0.0, 10.0),
+        "inside": rt.make_camera((0.37, 0.21, 0.11), (5, 0.2, 3), (0, 1, 0), 80.0, nx / ny, 0.0, 1.0),
+        "far":    rt.make_camera((2000, 300, 500), (0, 0, 0), (0, 1, 0), 0.6, nx / ny, 0.0, 2000.0),
+        "steep":  rt.make_camera((0.5, 30, 0.5), (0, 0, 0), (0, 0, 1), 35.0, nx / ny, 0.1, 30.0),
+        "no_big": rt.make_camera((12, 0.2, 1), (0, 0.2, 0), (0, 1, 0), 30.0, nx / ny, 0.0, 10.0),
+    }
+    cam = cams[view]
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, depth, counters=True)
+    assert cnt.hits > 0.2 * nx * ny * ns
+    boxes = {}
+    for cells in ("1", "0"):
+        monkeypatch.setenv("RT_BOX_CELLS", cells)
+        got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, depth, counters=1, variant=0)
+        assert np.array_equal(_bits(got), _bits(ref)), (view, cells, np.count_nonzero(_bits(got) != _bits(ref)))
+        assert st.rays == cnt.rays
+        boxes[cells] = st.box_tests
+    assert boxes["1"] < 0.7 * boxes["0"], boxes            # the prefilter was really in front of the box tests
+
+
 def test_camera_inside_scene_and_odd_image_sizes(rt, O):
     """Camera inside the sphere cloud (rays start inside group boxes), image sizes that are not multiples of 8."""
     rng = np.random.default_rng(77)
