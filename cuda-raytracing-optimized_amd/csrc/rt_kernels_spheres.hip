@@ -72,13 +72,20 @@ __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
 // the member's local row lr is global row global_row(lr)).  Called by every thread of a grid with its flat index `tid` of `nthreads`: a pixel the work
 // distribution loses then shows as NaN instead of as the previous frame's value.  The frame's first dispatch does this beside its compute (it stores no
 // pixel: 12 bus writes of 4 bytes per thread on the benchmark frame); a single-dispatch frame runs k_poison_fb in front of its kernel.
-__device__ __forceinline__ void poison_rows(const RtSphereParams& P, size_t tid, size_t nthreads) {
-    uint32_t* fbw = reinterpret_cast<uint32_t*>(P.fb);
-    const size_t row_words = (size_t)P.nx * 3, total = (size_t)P.part.local_rows * row_words;
+__device__ __attribute__((noinline)) void poison_words(uint32_t* fbw, int nx, RtPartition part, size_t tid, size_t nthreads) {
+    const size_t row_words = (size_t)nx * 3, total = (size_t)part.local_rows * row_words;
+    if (part.world == 1) {                                           // the member owns every row: one contiguous range
+        for (size_t k = tid; k < total; k += nthreads) fbw[k] = 0xFFFFFFFFu;
+        return;
+    }
     for (size_t k = tid; k < total; k += nthreads) {
         const int lr = (int)(k / row_words);
-        fbw[(size_t)global_row(P.part, lr) * row_words + (k - (size_t)lr * row_words)] = 0xFFFFFFFFu;
+        fbw[(size_t)global_row(part, lr) * row_words + (k - (size_t)lr * row_words)] = 0xFFFFFFFFu;
     }
+}
+// (a real function taking values: inlined into the persistent kernel's loop it cost that kernel 13 SGPR and 3 VGPR spills)
+__device__ __forceinline__ void poison_rows(const RtSphereParams& P, size_t tid, size_t nthreads) {
+    poison_words(reinterpret_cast<uint32_t*>(P.fb), P.nx, P.part, tid, nthreads);
 }
 __global__ void __launch_bounds__(256) k_poison_fb(const RtSphereParams P) {
     poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
@@ -1235,7 +1242,6 @@ template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
-    if (PHASE == 1 && P.poison_fb) poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
     const SceneLds S = stage_scene<false, SCENE>(P, smem, &unused);
 
     const bool cull = (cfg & 1) != 0;
@@ -1362,7 +1368,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         }
     };
 
+    // PHASE 1 poisons the host framebuffer beside its compute (poison_rows): 11.5 MB over the bus on the benchmark frame.  Not at the head of the kernel - every
+    // wave would sit behind its own stores at the first `s_waitcnt vmcnt(0)` (the scene staging), all 4096 at once: 0.11 ms - but from inside the loop,
+    // the waves taking turns over the first ~50 iterations: a wave's 2.8 KB are acknowledged long before its next queue grab waits for them.
+    uint32_t poison_at = (PHASE == 1 && P.poison_fb) ? 2u + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % 24u) : ~0u;
+    uint32_t iter_no = 0;
     while (true) {
+        if (PHASE == 1 && iter_no++ == poison_at) poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
         // ---- refill idle lanes --------------------------------------------------------------------------------
         const bool dbg_timers = DBG && wdbg && (cfg & (1 << 29)) == 0;          // RT_WAVE_DEBUG_LIGHT=1: time stamps of waves and pixels only (the section timers
                                                                                  // stretch a sparse step by 40 %: the light form keeps the frame's real proportions)
@@ -1531,6 +1543,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
         }
     }
 
+    if (PHASE == 1 && poison_at != ~0u && iter_no <= poison_at) poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);   // (left the loop before its turn)
     if (P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
@@ -1778,6 +1791,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         q.phase = 2;
+        static const bool dbg_phase1 = getenv("RT_WAVE_DEBUG_PHASE") && getenv("RT_WAVE_DEBUG_PHASE")[0] == '1';      // diagnostics: the time line of the FIRST dispatch
+        if (dbg_phase1) q.wave_dbg = nullptr;
         return launch_queue_kernel<2, 2, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg, caps);
     }
     bool classified = false;
