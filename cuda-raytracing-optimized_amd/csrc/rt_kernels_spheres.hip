@@ -189,9 +189,11 @@ struct Lane {
 
 // kernels.cu:549-555 + the head of color() :397-398: starts sample L.s of the lane's pixel
 struct SampleParams { rt_camera cam; int32_t nx, ny, rng_mode; };     // what start_sample reads of the kernel parameters
-template <typename PP>
+// COUNTER = false: the caller knows the stream is the reference's (the two dispatches of the cost-ordered frame exist in that mode only), and the
+// lane's pixel id is then not read at all
+template <bool COUNTER = true, typename PP>
 __device__ __forceinline__ void start_sample(const PP& P, Lane& L) {
-    if (P.rng_mode == RT_RNG_COUNTER) L.rng = sample_seed(L.pixelId, (uint32_t)L.s);
+    if (COUNTER && P.rng_mode == RT_RNG_COUNTER) L.rng = sample_seed(L.pixelId, (uint32_t)L.s);
     const float u = ((float)L.i + rnd(L.rng)) / (float)P.nx;
     const float v = ((float)L.j + rnd(L.rng)) / (float)P.ny;
     f3 d;
@@ -1298,7 +1300,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     L.col = F3(0, 0, 0);
     L.org = F3(0, 0, 0); L.dir = F3(0, 0, 1);
     int lr = 0;                         // local row of the lane's pixel (framebuffer row)
-    int chunk = 0, s_end = 0;           // the lane's work item: samples [chunk * spw, s_end) of its pixel
+    int chunk = 0, s_end_lane = 0;      // the lane's work item: samples [chunk * spw, end) of its pixel
+    // (only sample chunks end at a per-lane sample: every other form of the kernel ends all its pixels at the same one - a scalar, not a register per lane)
+    auto s_end_of = [&]() -> int { return CHUNKED ? s_end_lane : (PHASE == 1 ? P.s_split : (PHASE == 2 ? P.ns : min(P.ns, P.spw))); };
     uint32_t nrays = 0, groups_done = 0, boxes_done = 0;
     bool have_pixel = false;            // lane owns an unfinished pixel
     uint32_t pix_rays = 0;              // rays traced so far for the lane's current pixel
@@ -1342,8 +1346,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             if (DBG && P.counters && (isnan(L.pcolor.x) || isnan(L.pcolor.y) || isnan(L.pcolor.z))) ray_stat<DBG>(P, RT_STAT_NAN);      // kernels.cu:559-561
             L.col = L.col + L.pcolor;                                // kernels.cu:558
             L.s++;
-            if (L.s < s_end) {
-                if (now) start_sample(sample_params(), L); else need_sample = true;
+            if (L.s < s_end_of()) {
+                if (now) start_sample<PHASE == 0>(sample_params(), L); else need_sample = true;
             } else {
                 if (PHASE == 1) {                                    // first samples done: park the pixel (RNG state, running sum, cost)
                     const size_t px = (size_t)lr * P.nx + L.i;
@@ -1477,15 +1481,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 }
                 if (i < P.nx && lr < P.part.local_rows) {            // pixels of partial edge tiles are skipped
                     if (PHASE == 0) {
-                        s_end = min(P.ns, (chunk + 1) * P.spw);
+                        s_end_lane = min(P.ns, (chunk + 1) * P.spw);
                         init_pixel(P, L, i, global_row(P.part, lr), chunk * P.spw);
                         pix_rays = 0;
                     } else if (PHASE == 1) {
-                        s_end = P.s_split;
                         init_pixel(P, L, i, global_row(P.part, lr), 0);
                         pix_rays = 0;
                     } else {                                         // resume: the pixel's stream continues where phase 1 left it
-                        s_end = P.ns;
                         const float4 st4 = P.ord_state[opos];
                         L.i = i; L.j = global_row(P.part, lr);
                         L.pixelId = (uint32_t)(L.j * P.nx + i);
@@ -1502,7 +1504,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
                 }
             }
         }
-        if (need_sample) { start_sample(sample_params(), L); need_sample = false; }
+        if (need_sample) { start_sample<PHASE == 0>(sample_params(), L); need_sample = false; }
         const unsigned long long live_now = __ballot(have_pixel);
         if (dbg_timers) dbg_tm[7] += __builtin_amdgcn_s_memtime() - t_refill;
         if (live_now == 0ull) break;                                 // wave-uniform exit: idle lanes stay to help
@@ -1544,7 +1546,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
     }
 
     if (PHASE == 1 && poison_at != ~0u && iter_no <= poison_at) poison_rows(P, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);   // (left the loop before its turn)
-    if (P.counters) {
+    // (the launcher runs the DBG instantiation whenever counters are asked for: in the production one the three per-lane counters and their increments are dead code)
+    if (DBG && P.counters) {
         atomicAdd(&P.counters->rays, (unsigned long long)nrays);
         atomicAdd(&P.counters->prim_tests, (unsigned long long)nrays * (unsigned long long)P.n);
         atomicAdd(&P.counters->exec_tests, (unsigned long long)groups_done * 4ull);     // lane-parallel phase-1 tests executed
@@ -1613,7 +1616,9 @@ size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {                       /
 template <bool CHUNKED>
 static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned blocks, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg) {
     const size_t lds = (size_t)kWavesPerWg * kWaveScratch;          // only the per-wave scratch: the scene stays in global memory
-    hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, 1>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, 0x4444);
+    // (counters - and with them the reference's ray statistics - live in the diagnostic instantiation only)
+    if (q.counters != nullptr || q.wave_dbg != nullptr) hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, true, 1>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, 0x4444);
+    else hipLaunchKernelGGL((k_render_spheres_queue<0, 0, CHUNKED, false, 1>), dim3(blocks), dim3(kThreads), lds, stream, q, stride, cfg, chain_cfg, 0x4444);
     return hipGetLastError();
 }
 
