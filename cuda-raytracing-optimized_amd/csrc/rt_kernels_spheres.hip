@@ -145,16 +145,16 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
     if (SCENE == 2) {
-        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups + kCellTableWords / 4);
+        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups));
         for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += (int)blockDim.x) s_sph[k] = P.spheres[k];
         for (int k = threadIdx.x; k < P.n_padded; k += (int)blockDim.x) s_org[k] = P.orig[k];
-        for (int k = threadIdx.x; k < 3 * P.n_groups + kCellTableWords / 4; k += (int)blockDim.x) s_grp[k] = P.groups[k];     // (boxes + their cell tables)
+        for (int k = threadIdx.x; k < 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups); k += (int)blockDim.x) s_grp[k] = P.groups[k];     // (boxes + their cell tables)
         *after = nullptr;
         unsigned char* scratch = reinterpret_cast<unsigned char*>(s_org + P.n_padded);
         __syncthreads();
         return { s_sph, s_grp, P.mat_color, P.mat_type, s_org, P.slot_of, P.rad, scratch };
     }
-    float4* s_mat = s_grp + 3 * P.n_groups + kCellTableWords / 4;
+    float4* s_mat = s_grp + 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups);
     int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
     int*    s_org = s_typ + P.n_padded;
     float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
@@ -166,7 +166,7 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
     }
-    for (int k = threadIdx.x; k < 3 * P.n_groups + kCellTableWords / 4; k += (int)blockDim.x) s_grp[k] = P.groups[k];
+    for (int k = threadIdx.x; k < 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups); k += (int)blockDim.x) s_grp[k] = P.groups[k];
     for (int k = threadIdx.x; k < P.n; k += (int)blockDim.x) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
     *after = s_fb;                                                   // WITH_FB (tile kernel): kThreads x 3 floats of framebuffer staging
@@ -402,11 +402,12 @@ __device__ __forceinline__ uint32_t group_needs_shared(const SceneLds& S, int g0
 // the first / last cell, whose words reject nothing.
 template <int AX>
 __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& r, f3 org, f3 dn,
-                                                      float shared_lo, float shared_hi, uint32_t& boxes_done) {
+                                                      float shared_lo, float shared_hi, uint32_t& boxes_done, int word) {
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     constexpr int A1 = (AX + 1) % 3, A2 = (AX + 2) % 3;
     const float* f = reinterpret_cast<const float*>(S.grp + 3 * g0);
-    const uint32_t* tab = reinterpret_cast<const uint32_t*>(S.grp + 3 * P.n_groups);
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(S.grp + 3 * P.n_groups) + word;      // this pass' 32 groups: word `word` of every set
+    const int W = rt_cell_words(P.n_groups);
     const float s_near = bsign<AX>(r) ? shared_hi : shared_lo, s_far = bsign<AX>(r) ? shared_lo : shared_hi;
     const float in0 = fmaxf(__builtin_fmaf(s_near, comp<AX>(r.inv), -comp<AX>(r.cn)), 0.0f);
     const float out0 = fminf(__builtin_fmaf(s_far, comp<AX>(r.inv), -comp<AX>(r.cf)), r.cb);
@@ -417,7 +418,7 @@ __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, c
         // (a NaN goes to the permissive end: fmaxf / fminf return their other operand)
         const float c_lo = fminf(fmaxf(__builtin_fmaf(lo, P.cell_scale[q], P.cell_off[q]), 0.0f), (float)(kCellCount - 1));
         const float c_hi = fmaxf(fminf(__builtin_fmaf(hi, P.cell_scale[q], P.cell_off[q]), (float)(kCellCount - 1)), 0.0f);
-        return tab[2 * kCellCount * q + (int)c_hi] & tab[2 * kCellCount * q + kCellCount + (int)c_lo];
+        return tab[__umul24((uint32_t)(2 * kCellCount * q) + (uint32_t)c_hi, (uint32_t)W)] & tab[__umul24((uint32_t)(2 * kCellCount * q + kCellCount) + (uint32_t)c_lo, (uint32_t)W)];     // (24-bit multiply: full rate)
     };
     uint32_t cand = overlap(comp<A1>(org), comp<A1>(dn), 0) & overlap(comp<A2>(org), comp<A2>(dn), 1);
     if (!(in0 <= out0)) cand = 0u;                                   // the ray misses the slab (or leaves it behind its closest hit): the box test would skip every box
@@ -580,7 +581,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     // A scene of up to 32 small groups (the benchmark: 31) takes ONE pass of 32: one prefix sum, one list write, one synchronisation per ray batch instead of
     // two.  The list holds 64 x 16 + 64 entries; a pass of 32 whose pairs would not fit (every ray reaching more than half of the scene: not seen) is
     // split into its two halves of 16 groups (wave-uniform), like the passes of larger scenes.
-    const int pass_w = (P.n_groups - P.n_big_groups <= 32) ? 32 : kPassGroups;
+    const int pass_w = (P.n_groups - P.n_big_groups <= 32 || (cull && P.cell_on != 0)) ? 32 : kPassGroups;
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += pass_w) {
         const int ng = min(pass_w, P.n_groups - g0);
         // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
@@ -588,8 +589,8 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         const bool last_pass = g0 + pass_w >= P.n_groups || flush;
         uint32_t need_all = 0u;
         if (has_ray) {
-            if (cull && P.cell_on != 0) {                            // (<= 32 small groups: this is the only pass, g0 = n_big_groups; shared axis y)
-                need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done);
+            if (cull && P.cell_on != 0) {                            // (passes of 32 groups, pass k = word k of the cell sets; shared axis y)
+                need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done, (g0 - P.n_big_groups) >> 5);
             } else {
                 need_all = group_needs(P, S, g0, ng, br, cull);
                 boxes_done += (uint32_t)ng;
@@ -1590,7 +1591,7 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg) {
     // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
-    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 + (size_t)kCellTableWords * 4;
+    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 + (size_t)kCellCount * rt_cell_words(n_padded / kSphereGroup) * 16;
     const size_t scratch = (size_t)waves * kWaveScratch;
     if (scene == 1) return scratch;
     if (scene == 2) return test_data + (size_t)n_padded * 4 + scratch;

@@ -406,20 +406,21 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     // nothing it should not.
     constexpr double kCellSlack = 1.0e-3;
     c.cell_on = 0;
-    c.h_groups.resize((size_t)c.n_groups * 3 + kCellTableWords / 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    const int n_small_groups = c.n_groups - n_big_groups;
-    if (c.box_shared_axis == 2 && n_boxes > 0 && n_small_groups <= 32) {      // (the kernel instantiates the prefilter for a shared y axis only: spheres on a horizontal plane)
+    const int cell_words = rt_cell_words(c.n_groups);
+    c.h_groups.resize((size_t)c.n_groups * 3 + (size_t)kCellCount * cell_words, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    if (c.box_shared_axis == 2 && n_boxes > 0 && cell_words > 0) {      // (the kernel instantiates the prefilter for a shared y axis only: spheres on a horizontal plane)
         const int ax = c.box_shared_axis - 1;
         const int axes[2] = { (ax + 1) % 3, (ax + 2) % 3 };
+        const int W = cell_words;
         uint32_t* tab = reinterpret_cast<uint32_t*>(c.h_groups.data() + (size_t)c.n_groups * 3);
-        uint32_t all = 0;
-        for (int g = n_big_groups; g < c.n_groups; g++) if (c.h_groups[3 * g].x <= c.h_groups[3 * g].y) all |= 1u << (g - n_big_groups);
+        std::vector<char> real(c.n_groups, 0);
+        for (int g = n_big_groups; g < c.n_groups; g++) real[g] = c.h_groups[3 * g].x <= c.h_groups[3 * g].y;
         bool ok = true;
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < 2 && ok; q++) {
             const int a = axes[q];
             double amin = 1e300, amax = -1e300;
             for (int g = n_big_groups; g < c.n_groups; g++) {
-                if (!((all >> (g - n_big_groups)) & 1u)) continue;
+                if (!real[g]) continue;
                 amin = std::min(amin, (double)c.h_groups[3 * g + a].x);
                 amax = std::max(amax, (double)c.h_groups[3 * g + a].y);
             }
@@ -428,16 +429,14 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
             c.cell_scale[q] = (float)(1.0 / w);
             c.cell_off[q] = (float)(-amin / w);
             for (int cell = 0; cell < kCellCount; cell++) {
-                uint32_t begins = 0, ends = 0;
+                uint32_t* begins = tab + ((size_t)(2 * q) * kCellCount + cell) * W;
+                uint32_t* ends = tab + ((size_t)(2 * q + 1) * kCellCount + cell) * W;
                 for (int g = n_big_groups; g < c.n_groups; g++) {
-                    if (!((all >> (g - n_big_groups)) & 1u)) continue;
-                    if ((double)c.h_groups[3 * g + a].x <= amin + (cell + 1 + kCellSlack) * w) begins |= 1u << (g - n_big_groups);
-                    if ((double)c.h_groups[3 * g + a].y >= amin + (cell - kCellSlack) * w) ends |= 1u << (g - n_big_groups);
+                    if (!real[g]) continue;
+                    const int k = g - n_big_groups;
+                    if (cell == kCellCount - 1 || (double)c.h_groups[3 * g + a].x <= amin + (cell + 1 + kCellSlack) * w) begins[k >> 5] |= 1u << (k & 31);
+                    if (cell == 0 || (double)c.h_groups[3 * g + a].y >= amin + (cell - kCellSlack) * w) ends[k >> 5] |= 1u << (k & 31);
                 }
-                if (cell == kCellCount - 1) begins = all;
-                if (cell == 0) ends = all;
-                tab[2 * kCellCount * q + cell] = begins;
-                tab[2 * kCellCount * q + kCellCount + cell] = ends;
             }
         }
         const bool cells_off = getenv("RT_BOX_CELLS") && getenv("RT_BOX_CELLS")[0] == '0';     // (read at every init: the tests render with and without)

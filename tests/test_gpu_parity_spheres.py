@@ -237,18 +237,20 @@ def test_spheres_on_a_plane_share_a_box_slab(rt, O, axis):
     assert st.rays == cnt.rays
 
 
-@pytest.mark.parametrize("view", ["level", "below", "inside", "far", "steep", "no_big"])
-def test_cell_table_prefilter_of_the_group_boxes(rt, O, view, monkeypatch):
+@pytest.mark.parametrize("view,n", [("level", 430), ("below", 430), ("inside", 430), ("far", 430), ("steep", 430), ("no_big", 430),
+                                    ("level", 1500), ("inside", 1500), ("far", 3000), ("no_big", 3000)])
+def test_cell_table_prefilter_of_the_group_boxes(rt, O, view, n, monkeypatch):
     """Spheres resting on a horizontal plane in <= 32 groups (the benchmark's shape): the group box tests run behind the cell-table prefilter
     (group_needs_cells, rt_kernels_spheres.hip).  Views chosen against it: rays that run inside the slab of the small spheres, level with it
     (the slab interval is long, or unbounded when nothing big is hit: end points at infinity), from below the plane, from inside the slab,
-    from 2000 units away (the margin m exceeds a cell), straight down, and a scene without any big sphere (no bound at all).  Bit-exact
-    against the oracle, with the prefilter and without (RT_BOX_CELLS=0), ray counts equal."""
+    from 2000 units away (the margin m exceeds a cell), straight down, and a scene without any big sphere (no bound at all); 430 spheres (one
+    word per cell set, one pass) and 1500 / 3000 (several words, a pass of 32 groups per word).  Bit-exact against the oracle, with the
+    prefilter and without (RT_BOX_CELLS=0), ray counts equal."""
     rng = np.random.default_rng(4242)
-    n = 430
     sp = np.zeros(n, rt.sphere_dtype)
     mt = np.zeros(n, rt.material_dtype)
-    c = rng.uniform(-9, 9, (n, 3))
+    half = 9.0 * (n / 430.0) ** 0.5                      # (the same density at every size; 1500 / 3000 spheres: 94 / 188 groups = 3 / 6 words per cell set)
+    c = rng.uniform(-half, half, (n, 3))
     c[:, 1] = 0.2
     sp["center"] = c
     sp["radius"] = 0.2
