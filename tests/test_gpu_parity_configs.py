@@ -56,6 +56,24 @@ def test_c3_1000spp_frame_bit_exact_on_crops_and_pixels(rt, O):
     _check_pixels(O, sc, cam, opt, w, got, zip(rng.integers(0, w["nx"], 150), rng.integers(0, w["ny"], 150)), w["spp"], fb)
 
 
+@pytest.mark.parametrize("name,spp", [("C2", 100), ("C5", 16)])
+def test_whole_frames_equal_with_and_without_the_box_prefilter(rt, name, spp, monkeypatch):
+    """Size-independent check of the cell-table prefilter (group_needs_cells): it may only drop boxes the exact box test would drop too, so the
+    WHOLE benchmark frame - every pixel of 1200x800 at 100 spp, of 3840x2160 at 16 spp - must come out bit-equal with it and without it
+    (RT_BOX_CELLS=0: the uniform loop over all 31 boxes), and the reference's ray statistics must agree."""
+    frames, rays = {}, {}
+    for cells in ("1", "0"):
+        monkeypatch.setenv("RT_BOX_CELLS", cells)
+        w, b = _open(rt, name)
+        b.step(spp)
+        frames[cells] = b.image()
+        rays[cells] = b.counted(min(spp, 8))["rays"]
+        b.close()
+    assert not np.isnan(frames["1"]).any()
+    assert np.array_equal(_bits(frames["1"]), _bits(frames["0"])), np.count_nonzero(_bits(frames["1"]) != _bits(frames["0"]))
+    assert rays["1"] == rays["0"] and rays["1"] > 0
+
+
 def test_c5_frame_two_dispatch_and_full_4096spp_pixels(rt, O):
     """C5: 3840x2160, 488 spheres.  (a) 16 spp - the two-dispatch path with 8.3 M parked pixel states at this size - on four crops and 300
     random pixels; (b) the benchmark frame itself, 4096 spp (3.5 s on the GPU), on 40 single pixels: the glass rim with the longest chains of
