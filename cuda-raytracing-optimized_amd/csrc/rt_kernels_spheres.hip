@@ -29,6 +29,9 @@
 //     is unchanged; the explicit (t, original index) tie rule keeps the reference's first-index-wins order;
 //   * the group boxes are stored per AXIS as (lo, hi, lo): a ray reads (near, far) at an offset given by the sign of its direction; an axis on
 //     which all boxes agree (spheres on a plane) is evaluated once per pass; results are accumulated as sign bits (box_gap, group_needs);
+//   * scenes whose small spheres rest on a horizontal plane (the benchmark) run the box tests behind a cell-table prefilter (group_needs_cells): the part of the ray
+//     inside the spheres' slab has a bounding rectangle, per-cell sets of "boxes that begin below / end above" leave the 2-3 boxes it can overlap, and only those
+//     take the slab test - conservative on its own terms, so the pair set and the frame are unchanged;
 //   * framebuffer: the persistent kernels (default) store a finished pixel with ONE 12-byte store from the lane that owns it
 //     (pixels finish one by one, in cost order) - by default straight into the pinned host framebuffer (RtSphereParams::fb_global_rows);
 //     only the tile kernel (variant 1) transposes its 8x8 tile through LDS so that a wave writes row-contiguous dwords;
