@@ -650,7 +650,14 @@ void runRenderer(int ns, int tx, int ty) {
         static const bool fb_direct_env = !(getenv("RT_FB_DIRECT") && getenv("RT_FB_DIRECT")[0] == '0');
         int spw = ns, chunks = 1;               // sphere path, RT_RNG_COUNTER: samples per work item, work items per pixel
         if (c.is_spheres && c.opt.rng == RT_RNG_COUNTER && (c.opt.variant & 0xFF) == 0) {
-            const int want = c.opt.samples_per_item > 0 ? c.opt.samples_per_item : 4;
+            // default: 4 samples per item, but no more items than fill and balance the machine (~32 M): a 3840x2160x4096spp frame cut into 4-sample items
+            // would be 8.5 G items and a 100 GB buffer of partial sums - it takes 3 items per pixel instead
+            int want = c.opt.samples_per_item;
+            if (want <= 0) {
+                const long long pixels = std::max<long long>(1, (long long)d.fb_rows * c.nx);
+                const long long max_chunks = std::max<long long>(1, (32ll << 20) / pixels);
+                want = (int)std::max<long long>(4, (ns + max_chunks - 1) / max_chunks);
+            }
             if (want < ns) { spw = want; chunks = (ns + want - 1) / want; }
         }
         const int vk = c.opt.variant & 0xFF, vcb = (c.opt.variant >> 16) & 0xFF;
