@@ -487,7 +487,7 @@ def rmse(f, g):
 # per-function device probes (include/rt_probe.h)
 # ---------------------------------------------------------------------------------------------
 
-PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math", "ShadowRay", "PlaneHit", "SinCos")
+PROBE_SYMBOLS = [f"rtProbe{n}_{m}" for n in ("Rng", "DiskSphere", "GetRay", "SphereHit", "TriangleHit", "Bbox", "Scatter", "Math", "ShadowRay", "PlaneHit", "SinCos", "Schlick")
                  for m in ("parity", "fast")]
 
 
@@ -585,6 +585,13 @@ class Probe:
         s = np.zeros(n, np.float32); c = np.zeros(n, np.float32)
         self._fn("SinCos")(_p(y), C.c_int(n), _p(s), _p(c))
         return s, c
+
+    def schlick(self, cosine, ref_idx, u):
+        """schlick (material.h:9-13) with the device's powf(x, 5) (csrc/rt_glibc_powf.h), and `u < schlick` as the path decides it."""
+        c = _f32(cosine); r = _f32(ref_idx); u = _f32(u); n = len(c)
+        out = np.zeros(n, np.float32); above = np.zeros(n, np.int32)
+        self._fn("Schlick")(_p(c), _p(r), _p(u), C.c_int(n), _p(out), _p(above))
+        return out, above
 
     def math(self, a, b):
         a = _f32(a); b = _f32(b); n = len(a)

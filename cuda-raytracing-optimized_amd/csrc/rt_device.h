@@ -15,6 +15,11 @@
 
 #define RT_SINCOS_FN __device__ __forceinline__
 #include "rt_glibc_sincosf.h"      // glibc's sinf / cosf / sincosf restated (fp64 polynomial, the FMA build's fusions): the CPU side's bits
+// glibc's powf for the exponent 5 restated the same way (its log2 / exp2 tables in constant memory).  A real function: it runs only when the cheap
+// bracket of schlick_above cannot decide (about once per 10^6 calls), and its fp64 temporaries stay out of the shading code's register budget
+#define RT_POWF_FN __device__ __attribute__((noinline))
+#define RT_POWF_TABLE static __constant__ const
+#include "rt_glibc_powf.h"
 
 namespace rtd {
 
@@ -118,19 +123,31 @@ __device__ __forceinline__ void get_ray(const rt_camera& c, float s, float t, ui
 
 // ---- material.h -------------------------------------------------------------------------------
 
-// pow(x, 5.0f), material.h:12.  Evaluated in fp64 and rounded once: the correctly rounded value
-// except with probability ~2^-29.  glibc's powf (what the oracle calls) differs from that in
-// 0.07 % of arguments by one ulp, which can flip the `rnd < schlick` decision only when the
-// 24-bit draw lands between the two values (probability <= 2^-24 per affected call).
-__device__ __forceinline__ float pow5(float x) {
-    const double d = (double)x;
-    const double d2 = d * d;
-    return (float)(d2 * d2 * d);
-}
+// pow(x, 5.0f), material.h:12: the reference calls powf, which on the CPU side is glibc's; rt_glibc_powf.h restates that algorithm (equal to libm on
+// every float, tests/test_oracle_golden.py::test_glibc_powf5_twin_is_libm), so schlick is bit-exact like everything else on the path.
+__device__ __forceinline__ float pow5(float x) { return rt_glibc_powf5(x); }
 __device__ __forceinline__ float schlick(float cosine, float ref_idx) {     // material.h:9-13
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
     return r0 + (1.0f - r0) * pow5(1.0f - cosine);
+}
+// `u < schlick(cosine, ref_idx)` - the only use the path makes of schlick (material.h:58: rnd(...) < schlick(...)) - decided without running powf almost always:
+// the fp64 product x^5 rounded once lies within kPow5Bracket ulps of glibc's powf(x, 5) for every float x in [0, 2.5] (held on ALL of them by
+// tests/test_oracle_golden.py::test_glibc_powf5_twin_is_libm: the largest distance is 1 ulp), and p -> fl(r0 + fl(k p)) is monotone (each rounding is), so
+// the reference's schlick lies between the values at the bracket's two ends; when `u` is on the same side of both, that is the answer.  Otherwise - u within
+// a few ulps of the threshold: u is a multiple of 2^-24, about one call in a million - the exact function runs.  Same bits as the plain comparison.
+constexpr uint32_t kPow5Bracket = 2u;
+__device__ __forceinline__ bool schlick_above(float u, float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    const float k = 1.0f - r0, x = 1.0f - cosine;
+    const double d = (double)x, d2 = d * d;
+    const uint32_t pb = __float_as_uint((float)(d2 * d2 * d));
+    const float s_a = r0 + k * __uint_as_float(pb > kPow5Bracket ? pb - kPow5Bracket : 0u);
+    const float s_b = r0 + k * __uint_as_float(pb + kPow5Bracket);
+    const bool a = u < s_a, b = u < s_b;
+    if (x >= 0.0f && x <= 2.5f && a == b) return a;
+    return u < schlick(cosine, ref_idx);
 }
 __device__ __forceinline__ f3 refract(f3 uv, f3 n, float etai_over_etat) { // material.h:15-21
     const float cos_theta = fminf(dot(-uv, n), 1.0f);
@@ -166,7 +183,7 @@ __device__ __forceinline__ bool fresnel_layer(f3 normal, bool inside, f3 wo, flo
     const float cos_theta = fminf(dot(-wo, normal), 1.0f);
     const float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
     bool r = etai_over_etat * sin_theta > 1.0f;
-    if (!r) r = rnd(rng) < schlick(cos_theta, etai_over_etat);
+    if (!r) { const float u = rnd(rng); r = schlick_above(u, cos_theta, etai_over_etat); }
     return r;
 }
 
@@ -213,13 +230,10 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
     default:               bsdf = B_SSS; ior = 1.333f; tint = F3(1, 1, 1); absorption = F3(0.9f, 0.3f, 0.02f); break;
     }
 
-    if (bsdf == B_COAT) bsdf = fresnel_layer(normal, inside, wo, ior, rng) ? B_GLOSSY : B_DIFFUSE;     // material.h:62-70
-
     // Lanes of different materials reach their random_in_unit_sphere draw (diffuse bounce, metal fuzz, subsurface event) in
     // different branches; a wave would run the rejection loop once per branch (max-over-lanes iterations each time).  The
-    // draw is hoisted to ONE place: everything a lane draws BEFORE it (coat layer above, subsurface distance here) is
-    // done first, what it draws after it (Fresnel choice of the dielectrics) comes after - every lane's own draw order
-    // is the reference's.
+    // draw is hoisted to ONE place: everything a lane draws BEFORE it (coat layer, subsurface distance, and the Fresnel choice below) is
+    // done first - every lane's own draw order is the reference's.
     bool scattered = false;
     if (bsdf == B_DIELECTRIC || bsdf == B_SSS) {             // dielectric_bsdf (material.h:73-92) / subsurface_dielectric_bsdf (:119-143)
         if (inside) {
@@ -234,6 +248,11 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
             }
         }
     }
+    // The Fresnel choice (fresnel_layer: at most one draw, and powf) of the coat presets (material.h:62-70, before the layer's own scatter) and of the
+    // dielectrics (material.h:80,131, the path's last draw: a lane that takes it never draws a unit-sphere point) at ONE site: a lane calls it at most once.
+    bool fresnel = false;
+    if (bsdf == B_COAT || ((bsdf == B_DIELECTRIC || bsdf == B_SSS) && !scattered)) fresnel = fresnel_layer(normal, inside, wo, ior, rng);
+    if (bsdf == B_COAT) bsdf = fresnel ? B_GLOSSY : B_DIFFUSE;
     f3 rs = F3(0, 0, 0);
     if (bsdf == B_DIFFUSE || (bsdf == B_GLOSSY && fuzz > 0.0001f) || scattered) rs = random_in_unit_sphere(rng);
 
@@ -248,7 +267,7 @@ __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 h
     } else if (scattered) {
         v = rs;
         normalise = false;                                   // material.h:128: wi is NOT normalised
-    } else if (fresnel_layer(normal, inside, wo, ior, rng)) {
+    } else if (fresnel) {
         v = reflect(wo, normal);                             // glossy_bsdf, fuzz 0
         thr = thr * tint;
     } else {

@@ -1591,6 +1591,7 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 }
 }  // namespace
 
+constexpr size_t kStaticLds = 1024;          // what the kernels declare statically beside the dynamic allocation (the queue words), rounded up
 static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg) {
     // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
@@ -1604,7 +1605,7 @@ static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int wa
 
 #if defined(RT_MODE_PARITY)
 size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {                       // of the smallest LDS-resident form: beyond it the scene is read from global memory
-    return lds_bytes(n_padded, n, false, 2, 8);
+    return lds_bytes(n_padded, n, false, 2, 8) + kStaticLds;
 }
 #endif
 
@@ -1672,7 +1673,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     const bool legacy = cb_bits != 0 && cb_bits != 255;
     if (legacy) kind = 1;                       // the brute-force A/B scans live in the tile kernel only
     if (p.global_scene) kind = 0;               // scenes beyond the LDS: the persistent kernel only
-    const size_t kLdsPerCu = 160 * 1024;
+    const size_t kLdsPerCu = 160 * 1024 - kStaticLds;
     if (lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) > kLdsPerCu) kind = 0;        // the tile kernel only knows the full copy
     // The persistent kernel's workgroup is a whole CU's worth of waves (16: the launch bound's 4 per SIMD) around ONE scene copy - 88 KB of per-wave scratch
     // leave 72 KB for the scene: the full copy up to ~1200 spheres (60 bytes per sphere), the hybrid one (what a sphere TEST reads in the LDS, what only a HIT

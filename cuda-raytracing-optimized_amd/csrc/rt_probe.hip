@@ -149,6 +149,13 @@ __global__ void k_sincos(const float* y, int n, float* s_out, float* c_out) {
     s_out[k] = s; c_out[k] = c;
 }
 
+__global__ void k_schlick(const float* cosine, const float* ref_idx, const float* u, int n, float* out, int* above) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    out[k] = schlick(cosine[k], ref_idx[k]);
+    if (u && above) above[k] = schlick_above(u[k], cosine[k], ref_idx[k]) ? 1 : 0;
+}
+
 __global__ void k_shadow_ray(rt_sphere light, rt_vec3 lightColor, const float* org, const float* atten, const float* normal,
                              const uint32_t* states, int n, float* out9, int* ok, uint32_t* st_after) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,6 +267,13 @@ void PROBE(rtProbeSinCos)(const float* y_, int n, float* s_out, float* c_out) {
     auto y = in(y_, n);
     auto a = outb(s_out, n); auto b = outb(c_out, n);
     hipLaunchKernelGGL(k_sincos, grid_for(n), dim3(256), 0, 0, y.d, n, a.d, b.d);
+    sync();
+}
+
+void PROBE(rtProbeSchlick)(const float* cosine_, const float* ref_idx_, const float* u_, int n, float* out_, int* above_) {
+    auto a = in(cosine_, n); auto b = in(ref_idx_, n); auto u = in(u_, n);
+    auto c = outb(out_, n); auto d = outb(above_, n);
+    hipLaunchKernelGGL(k_schlick, grid_for(n), dim3(256), 0, 0, a.d, b.d, u.d, n, c.d, d.d);
     sync();
 }
 

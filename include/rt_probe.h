@@ -21,6 +21,7 @@
  *                                                             cosAMax, number of draws consumed; generated = its bool result)
  *   rtProbePlaneHit     planeHit                              intersections.h:43-52
  *   rtProbeSinCos       sinf / cosf of generateShadowRay      kernels.cu:378-379 (glibc's algorithm restated: csrc/rt_glibc_sincosf.h)
+ *   rtProbeSchlick      schlick (with its powf(x, 5))         material.h:9-13 (glibc's powf restated: csrc/rt_glibc_powf.h)
  */
 #ifndef RT_PROBE_H
 #define RT_PROBE_H
@@ -50,7 +51,9 @@ void rtProbeMath##sfx(const float* a, const float* b, int n, float* quot, float*
 void rtProbeShadowRay##sfx(const rt_sphere* light, const rt_vec3* lightColor, const float* org3, const float* atten3, const float* normal3, \
                            const uint32_t* states, int n, float* out9, int* generated, uint32_t* st_after); \
 void rtProbePlaneHit##sfx(const rt_plane* planes, const float* org3, const float* dir3, const float* tmin, const float* tmax, int n, float* t_out); \
-void rtProbeSinCos##sfx(const float* y, int n, float* sin_out, float* cos_out);
+void rtProbeSinCos##sfx(const float* y, int n, float* sin_out, float* cos_out); \
+/* out = schlick(cosine, ref_idx); above = (u < schlick(cosine, ref_idx)) as the path decides it (rt_device.h schlick_above) */ \
+void rtProbeSchlick##sfx(const float* cosine, const float* ref_idx, const float* u, int n, float* out, int* above);
 
 RT_PROBE_DECL(_parity)
 RT_PROBE_DECL(_fast)

@@ -805,3 +805,70 @@ long orc_glibc_sincosf_twin_mismatches(int mode, long k0, long k1, float step, f
 void orc_libm_sincosf(const float* y, int n, float* s, float* c) {
     for (int k = 0; k < n; k++) { s[k] = sinf(y[k]); c[k] = cosf(y[k]); }
 }
+
+/* ---- the device's powf(x, 5), checked against THIS machine's libm ---------------------------------------------------------------------
+ * cuda-raytracing-optimized_amd/csrc/rt_glibc_powf.h restates glibc's powf for the exponent 5 (orc_schlick above calls powf: material.h:12) for the
+ * device; the same text is compiled here for the host and compared with libm.  Test infrastructure (tests/test_oracle_golden.py). */
+#define RT_POWF_FN static inline
+#include "../cuda-raytracing-optimized_amd/csrc/rt_glibc_powf.h"
+
+float orc_glibc_powf5_twin(float x) { return rt_glibc_powf5(x); }
+
+#include <pthread.h>
+typedef struct { uint64_t lo, hi, stride; long bad; uint32_t first_bad; uint32_t max_ulps; } powf5_job;
+static void* powf5_worker(void* arg) {
+    powf5_job* j = (powf5_job*)arg;
+    for (uint64_t b = j->lo; b < j->hi; b += j->stride) {
+        const uint32_t u = (uint32_t)b;
+        float x, t, l;
+        memcpy(&x, &u, 4);
+        t = rt_glibc_powf5(x);
+        l = powf(x, 5.0f);
+        if (memcmp(&t, &l, 4) && !(t != t && l != l)) {           /* (NaN payloads: any NaN equals any NaN) */
+            if (j->bad == 0) j->first_bad = u;
+            j->bad++;
+        }
+        if (x >= 0.0f && x <= 2.5f) {                              /* the bracket of rt_device.h schlick_above: |libm - fl(x^5 in fp64)| in ulps */
+            const double d = (double)x, d2 = d * d;
+            const float f = (float)(d2 * d2 * d);
+            uint32_t fb, lb;
+            memcpy(&fb, &f, 4); memcpy(&lb, &l, 4);
+            const uint32_t dist = fb > lb ? fb - lb : lb - fb;
+            if (dist > j->max_ulps) j->max_ulps = dist;
+        }
+    }
+    return 0;
+}
+/* Bit patterns [lo, hi) in steps of `stride`, split over `threads` host threads.  Returns the number of arguments on which the twin differs from
+ * libm's powf(x, 5.0f) in any bit; *first_bad receives the bit pattern of one such argument; *max_ulps is raised to the largest distance, in units of
+ * the last place, between libm's result and the fp64 product x^5 rounded once, over the arguments in [0, 2.5]. */
+long orc_glibc_powf5_twin_mismatches(uint64_t lo, uint64_t hi, uint64_t stride, int threads, uint32_t* first_bad, uint32_t* max_ulps) {
+    pthread_t th[64];
+    powf5_job job[64];
+    long bad = 0;
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    const uint64_t steps = (hi - lo + stride - 1) / stride, per = (steps + threads - 1) / threads;
+    for (int k = 0; k < threads; k++) {
+        job[k].lo = lo + (uint64_t)k * per * stride;
+        job[k].hi = job[k].lo + per * stride < hi ? job[k].lo + per * stride : hi;
+        if (job[k].lo > hi) job[k].lo = hi;
+        job[k].stride = stride; job[k].bad = 0; job[k].first_bad = 0; job[k].max_ulps = 0;
+        pthread_create(&th[k], 0, powf5_worker, &job[k]);
+    }
+    for (int k = 0; k < threads; k++) {
+        pthread_join(th[k], 0);
+        if (job[k].bad && bad == 0 && first_bad) *first_bad = job[k].first_bad;
+        bad += job[k].bad;
+        if (max_ulps && job[k].max_ulps > *max_ulps) *max_ulps = job[k].max_ulps;
+    }
+    return bad;
+}
+
+/* libm's powf(x, 5.0f) and orc_schlick over arrays (the expected values of the device probes) */
+void orc_libm_powf5(const float* x, int n, float* out) {
+    for (int k = 0; k < n; k++) out[k] = powf(x[k], 5.0f);
+}
+void orc_schlick_array(const float* cosine, const float* ref_idx, int n, float* out) {
+    for (int k = 0; k < n; k++) out[k] = orc_schlick(cosine[k], ref_idx[k]);
+}

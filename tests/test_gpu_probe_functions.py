@@ -1,7 +1,7 @@
 """GPU parity per FUNCTION of the hot path (SURVEY.md §8a rows a-6 .. a-13): each device function is
 run by itself through the probe C-ABI (include/rt_probe.h) on seeded random + edge-case inputs and
-compared with the CPU oracle.  PARITY build: bit-exact (integer work and IEEE fp32 +,-,*,/,sqrt).
-pow(x,5) is the one libm call on this path: 1 ulp allowed (see rt_device.h pow5)."""
+compared with the CPU oracle.  PARITY build: bit-exact (integer work and IEEE fp32 +,-,*,/,sqrt; the libm calls of the path - powf(x, 5), sinf,
+cosf - are glibc's algorithms restated for the device: csrc/rt_glibc_powf.h, csrc/rt_glibc_sincosf.h)."""
 import ctypes as C
 
 import numpy as np
@@ -30,7 +30,7 @@ def lib(O):
     return O.load_oracle()
 
 
-def test_basic_math_is_ieee(probe):
+def test_basic_math_is_ieee(probe, lib):
     rng = np.random.default_rng(1)
     a = rng.uniform(-3, 3, N).astype(np.float32)
     b = rng.uniform(0.01, 5, N).astype(np.float32) * rng.choice([-1, 1], N).astype(np.float32)
@@ -40,8 +40,49 @@ def test_basic_math_is_ieee(probe):
     v = np.stack([a, b, a - b], 1)
     ln = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
     assert np.array_equal(_bits(u3), _bits(v / ln[:, None]))
-    exact = (a.astype(np.float64) ** 5).astype(np.float32)
-    assert np.array_equal(_bits(p5), _bits(exact))
+    lp = np.zeros(N, np.float32)                                          # powf(a, 5.0f) of this machine's libm (material.h:12 calls it)
+    lib.orc_libm_powf5.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_libm_powf5(a.ctypes.data, N, lp.ctypes.data)
+    assert np.array_equal(_bits(p5), _bits(lp))
+
+
+def test_powf5_and_schlick_are_the_cpu_libm(probe, lib):
+    """material.h:9-13: schlick calls pow(1 - cosine, 5.0f) - powf, glibc's on the CPU side.  The device runs that algorithm restated
+    (csrc/rt_glibc_powf.h; on the host the same text equals libm on every float: test_glibc_powf5_twin_is_libm).  Here the DEVICE's bits: powf(x, 5) on
+    2^20 arguments of [0, 2] (every 1 - min(cos, 1)), on 2^18 spread over all floats (negative, subnormal, huge, inf, NaN) and on the boundary cases;
+    schlick on 2^20 (cosine, ref_idx) pairs - glass and its reciprocal, the presets' indices, random ones - against orc_schlick.  Every bit equal."""
+    rng = np.random.default_rng(5)
+    xb = np.concatenate([rng.integers(0, 0x40000001, 1 << 20, dtype=np.uint64), rng.integers(0, 1 << 32, 1 << 18, dtype=np.uint64),
+                         np.array([0, 0x80000000, 1, 0x007FFFFF, 0x00800000, 0x3F800000, 0x3F7FFFFF, 0x3F800001, 0x40000000, 0x7F800000, 0xFF800000,
+                                   0x7FC00000, 0x4C000000, 0x4B800000, 0x20000000, 0x21000000, 0x21800000, 0xBF800000, 0xC0000000], np.uint64)]).astype(np.uint32)
+    x = xb.view(np.float32)
+    pad = np.ones(len(x), np.float32)
+    _, _, p5, _ = probe.math(x, pad)
+    lp = np.zeros(len(x), np.float32)
+    lib.orc_libm_powf5.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_libm_powf5(x.ctypes.data, len(x), lp.ctypes.data)
+    nan = np.isnan(lp)
+    assert np.array_equal(np.isnan(p5), nan)
+    assert np.array_equal(_bits(p5)[~nan], _bits(lp)[~nan])
+    n = 1 << 20
+    cosine = np.concatenate([rng.uniform(0.0, 1.0, n - 4096), 1.0 - rng.uniform(0, 1, 2048) ** 6, rng.uniform(-1e-3, 0.0, 2040),
+                             np.array([0.0, 1.0, 0.5, 1e-8, 1.0 - 2.0 ** -24, 2.0 ** -24, -0.0, 0.99999994], np.float64)]).astype(np.float32)
+    idx = rng.choice(np.array([1.5, 1.0 / 1.5, 1.1, 1.0 / 1.1, 1.333, 1.0 / 1.333], np.float32), n)
+    idx[::7] = rng.uniform(0.3, 3.0, len(idx[::7])).astype(np.float32)
+    want = np.zeros(n, np.float32)
+    lib.orc_schlick_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_schlick_array(cosine.ctypes.data, idx.ctypes.data, n, want.ctypes.data)
+    # the path only ever asks `rnd < schlick` (material.h:58), and decides it from a bracket around a cheap x^5 unless the draw is within a few ulps of
+    # the threshold (rt_device.h schlick_above): draws AT the threshold, one and two steps of the 2^-24 grid and of the float grid beside it, and random ones
+    u = rng.integers(0, 1 << 24, n).astype(np.float32) / np.float32(16777216.0)
+    near = np.floor(want.astype(np.float64) * 16777216.0)
+    sel = np.arange(n) % 4
+    u = np.where(sel == 1, ((near + rng.integers(-2, 3, n)) / 16777216.0).astype(np.float32), u)
+    u = np.where(sel == 2, (_bits(want).astype(np.int64) + rng.integers(-3, 4, n)).clip(0, 0x7F7FFFFF).astype(np.uint32).view(np.float32), u).astype(np.float32)
+    got, above = probe.schlick(cosine, idx, u)
+    assert np.array_equal(_bits(got), _bits(want))
+    assert np.array_equal(above != 0, u < want)
+    assert (u == want).sum() > 1000 and (above != 0).sum() > n // 8 and (above == 0).sum() > n // 8
 
 
 def test_rng_known_answers(probe, lib):

@@ -194,3 +194,24 @@ def test_glibc_sincosf_twin_is_libm(O):
     lib.orc_glibc_sincosf_twin.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     assert lib.orc_glibc_sincosf_twin(121.0, C.byref(s), C.byref(c)) == 0          # beyond the restated range: the caller falls back
     assert lib.orc_glibc_sincosf_twin(float("inf"), C.byref(s), C.byref(c)) == 0
+
+
+def test_glibc_powf5_twin_is_libm(O):
+    """cuda-raytracing-optimized_amd/csrc/rt_glibc_powf.h - the powf(x, 5.0f) the DEVICE computes in schlick (material.h:12) - compiled for the host
+    (oracle/rt_oracle.c includes the same text) equals this machine's libm powf(x, 5.0f) in every bit on ALL floats of [0, 2.5] - everything
+    1 - min(cos, 1) can be - and on every 61st bit pattern of the other floats (negative, subnormal, overflowing, inf; NaN against NaN)."""
+    import ctypes as C
+    import os
+    lib = O.load_oracle()
+    f = lib.orc_glibc_powf5_twin_mismatches
+    f.restype = C.c_long
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    bad, ulps = C.c_uint32(0), C.c_uint32(0)
+    threads = min(8, os.cpu_count() or 1)
+    assert f(0, 0x40200001, 1, threads, C.byref(bad), C.byref(ulps)) == 0, hex(bad.value)         # [0, 2.5]
+    assert f(0, 1 << 32, 61, threads, C.byref(bad), C.byref(ulps)) == 0, hex(bad.value)
+    # rt_device.h schlick_above decides `u < schlick` from the fp64 product x^5 and a bracket of kPow5Bracket = 2 ulps around it: libm's powf must lie inside
+    assert 1 <= ulps.value <= 2, ulps.value
+    lib.orc_glibc_powf5_twin.restype = C.c_float
+    lib.orc_glibc_powf5_twin.argtypes = [C.c_float]
+    assert lib.orc_glibc_powf5_twin(0.5) == 0.03125 and lib.orc_glibc_powf5_twin(-2.0) == -32.0 and lib.orc_glibc_powf5_twin(0.0) == 0.0

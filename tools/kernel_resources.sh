@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${3:-/tmp/kres_${TU}_${MODE}.s}
 DEF=-DRT_MODE_PARITY; FP="-ffp-contract=off"
 if [ "$MODE" = fast ]; then DEF=-DRT_MODE_FAST; FP="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"; fi
-hipcc --offload-arch=gfx950 -O3 -std=c++17 $DEF $FP -fno-slp-vectorize -fno-vectorize --cuda-device-only -S \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 $EXTRA $DEF $FP -fno-slp-vectorize -fno-vectorize --cuda-device-only -S \
     "$ROOT/cuda-raytracing-optimized_amd/csrc/rt_kernels_${TU}.hip" -o "$OUT"
 python3 - "$OUT" <<'PY'
 import re, sys
