@@ -9,6 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIB = os.path.join(_HERE, "liboracle.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libref.so")
+REF_MAIN_LIB = os.path.join(_HERE, "_ref", "libref_main.so")
 
 
 def _pkg():
@@ -142,8 +143,62 @@ def load_ref():
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.POINTER(orc_counters)]
         lib.ref_render_mesh.restype = None
+        # the reference's host I/O (staircase_scene.h: loadBVH, writePPM, setup_camera)
+        lib.ref_load_bvh.argtypes = [C.c_char_p, C.POINTER(C.c_int)]; lib.ref_load_bvh.restype = C.c_void_p
+        lib.ref_bvh_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _fp]; lib.ref_bvh_copy.restype = None
+        lib.ref_bvh_free.argtypes = [C.c_void_p]; lib.ref_bvh_free.restype = None
+        lib.ref_write_ppm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_long]; lib.ref_write_ppm.restype = C.c_long
+        lib.ref_setup_camera.argtypes = [C.c_int, C.c_int, C.POINTER(rt.camera)]; lib.ref_setup_camera.restype = None
         _ref = lib
     return _ref
+
+
+def ref_load_bvh(path):
+    """The reference's loadBVH (staircase_scene.h:75-101) on `path`: (triangles, nodes, bounds6, nppl), or None when it refuses the file."""
+    rt = _pkg()
+    ref = load_ref()
+    counts = (C.c_int * 3)()
+    h = ref.ref_load_bvh(os.fsencode(path), counts)
+    if not h:
+        return None
+    tris = np.zeros(counts[0], rt.triangle_dtype); bvh = np.zeros(counts[1], rt.bvh_node_dtype); bounds = (C.c_float * 6)()
+    ref.ref_bvh_copy(h, tris.ctypes.data, bvh.ctypes.data, bounds)
+    ref.ref_bvh_free(h)
+    return tris, bvh, np.array(bounds[:], np.float32), counts[2]
+
+
+def ref_write_ppm(fb):
+    """The bytes the reference's writePPM (staircase_scene.h:32-43) sends to std::cout for the framebuffer fb[ny][nx][3]."""
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    ref = load_ref()
+    n = ref.ref_write_ppm(fb.shape[1], fb.shape[0], fb.ctypes.data, None, 0)
+    buf = C.create_string_buffer(n)
+    ref.ref_write_ppm(fb.shape[1], fb.shape[0], fb.ctypes.data, buf, n)
+    return buf.raw[:n]
+
+
+def ref_setup_camera(nx, ny):
+    cam = _pkg().camera()
+    load_ref().ref_setup_camera(nx, ny, C.byref(cam))
+    return cam
+
+
+_ref_main = None
+
+
+def have_ref_main():
+    return os.path.exists(REF_MAIN_LIB)
+
+
+def load_ref_main():
+    """The reference's main.cpp (its REF_00.01 reader / writer) behind a C shim; only where oracle/_ref/libref_main.so was built."""
+    global _ref_main
+    if _ref_main is None:
+        lib = C.CDLL(REF_MAIN_LIB)
+        lib.ref_load_reference.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]; lib.ref_load_reference.restype = C.c_int
+        lib.ref_save_reference.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]; lib.ref_save_reference.restype = None
+        _ref_main = lib
+    return _ref_main
 
 
 def f3(v):

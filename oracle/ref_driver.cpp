@@ -583,3 +583,54 @@ void ref_render_mesh(const rt_triangle* tris_, const rt_bvh_node* bvh_, int num_
 }
 
 } /* extern "C" */
+
+/* ---- the host I/O either side of the path, the reference's OWN code ----------------------------------------------
+ * staircase_scene.h is #included above, so loadBVH (:75-101), writePPM (:32-43) and setup_camera (:62-73) are the reference's functions as they
+ * are; these wrappers only move data across the C boundary.  They pin cuda-raytracing-optimized_amd/host/ (rtLoadBvhFile / rtSaveBvhFile,
+ * rtWritePPM, rtStaircaseCamera): tests/test_oracle_vs_ref.py, and the fixtures oracle/gen_golden_hostio.py mints from them. */
+#include <iostream>
+
+extern "C" {
+
+/* loadBVH on `path`.  Returns an opaque handle (NULL when loadBVH refuses the file); counts3 = numTris, numBvhNodes, numPrimitivesPerLeaf. */
+void* ref_load_bvh(const char* path, int counts3[3]) {
+    mesh* m = new mesh();
+    int nppl = 0;
+    {   /* loadBVH reports a bad header on std::cerr: keep the test log quiet */
+        std::stringstream sink;
+        std::streambuf* old = std::cerr.rdbuf(sink.rdbuf());
+        const bool ok = std::ifstream(path).good() && loadBVH(path, *m, nppl);
+        std::cerr.rdbuf(old);
+        if (!ok) { delete m; return nullptr; }
+    }
+    counts3[0] = m->numTris; counts3[1] = m->numBvhNodes; counts3[2] = nppl;
+    return m;
+}
+/* copies what loadBVH filled in: triangle[numTris], bvh_node[numBvhNodes], bounds (min, max) */
+void ref_bvh_copy(const void* handle, rt_triangle* tris, rt_bvh_node* bvh, float bounds6[6]) {
+    const mesh* m = static_cast<const mesh*>(handle);
+    memcpy(tris, m->tris, sizeof(triangle) * (size_t)m->numTris);
+    memcpy(bvh, m->bvh, sizeof(bvh_node) * (size_t)m->numBvhNodes);
+    memcpy(bounds6, &m->bounds, sizeof(bbox));
+}
+void ref_bvh_free(void* handle) { delete static_cast<mesh*>(handle); }      /* mesh::~mesh frees what loadBVH allocated */
+
+/* writePPM(nx, ny, colors) with std::cout captured.  Returns the number of bytes it wrote; up to `cap` of them land in `out`. */
+long ref_write_ppm(int nx, int ny, const float* colors, char* out, long cap) {
+    std::stringstream buf;
+    std::streambuf* old = std::cout.rdbuf(buf.rdbuf());
+    writePPM(nx, ny, reinterpret_cast<const vec3*>(colors));
+    std::cout.rdbuf(old);
+    const std::string s = buf.str();
+    if (out && cap > 0) memcpy(out, s.data(), (size_t)((long)s.size() < cap ? (long)s.size() : cap));
+    return (long)s.size();
+}
+
+/* setup_camera(nx, ny), the sizes routed through volatile so that the constructor runs at run time (as in ref_make_camera) */
+void ref_setup_camera(int nx, int ny, rt_camera* out) {
+    volatile int vx = nx, vy = ny;
+    const camera c = setup_camera(vx, vy);
+    memcpy(out, &c, sizeof c);
+}
+
+}  // extern "C"

@@ -215,3 +215,30 @@ def test_glibc_powf5_twin_is_libm(O):
     lib.orc_glibc_powf5_twin.restype = C.c_float
     lib.orc_glibc_powf5_twin.argtypes = [C.c_float]
     assert lib.orc_glibc_powf5_twin(0.5) == 0.03125 and lib.orc_glibc_powf5_twin(-2.0) == -32.0 and lib.orc_glibc_powf5_twin(0.0) == 0.0
+
+
+def test_host_io_against_fixtures_minted_from_the_reference_code(rt, tmp_path):
+    """tests/golden/hostio* (oracle/gen_golden_hostio.py): a BVH_00.04 file together with the arrays the REFERENCE's loadBVH read from it, the bytes its
+    writePPM printed and the REF_00.01 file its saveReference wrote for a seeded framebuffer, its setup_camera at four sizes - held against
+    cuda-raytracing-optimized_amd/host (rtLoadBvhFile / rtSaveBvhFile, rtWritePPM, rtSaveReference / rtLoadReference, rtStaircaseCamera) without the
+    reference being present (staircase_scene.h:32-43,62-101; main.cpp:25-60)."""
+    import os
+    g = np.load(os.path.join(G, "hostio.npz"))
+    bvh_file = os.path.join(G, "hostio_small.bvh")
+    hm = rt.HostMesh.load(bvh_file)
+    assert hm.nppl == int(g["nppl"]) and hm.tris.tobytes() == g["tris"].tobytes() and hm.bvh.tobytes() == g["bvh"].tobytes()
+    assert bytes(hm.view.bounds) == g["bounds"].tobytes()
+    again = str(tmp_path / "again.bvh")
+    assert hm.save(again) == 0 and open(again, "rb").read() == open(bvh_file, "rb").read()      # our writer reproduces the file the reference accepted
+    hm.close()
+    fb = g["fb"]
+    ppm = str(tmp_path / "o.ppm")
+    assert rt.write_ppm(ppm, fb) == 0
+    assert open(ppm, "rb").read() == open(os.path.join(G, "hostio_small.ppm"), "rb").read()
+    ref = str(tmp_path / "o.ref")
+    assert rt.save_reference(ref, fb) == 0
+    assert open(ref, "rb").read() == open(os.path.join(G, "hostio_small.ref"), "rb").read()
+    rc, back = rt.load_reference(os.path.join(G, "hostio_small.ref"), fb.shape[1], fb.shape[0])
+    assert rc == 0 and back.tobytes() == fb.tobytes()
+    for (nx, ny), want in zip(g["cam_sizes"], g["cams"]):
+        assert bytes(rt.staircase_camera(int(nx), int(ny))) == want.tobytes(), (nx, ny)

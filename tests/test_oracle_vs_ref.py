@@ -205,3 +205,81 @@ def test_generate_shadow_ray_oracle_equals_reference_twin(rt):
             n_rej += 1
             assert ra[5] == 2
     assert n_gen > 500 and n_nan > 100 and n_rej > 100
+
+
+# ---- the host I/O either side of the path, against the reference's own code -----------------------------------------
+
+def test_bvh_file_written_here_loads_through_the_reference_loader(rt, tmp_path):
+    """rtSaveBvhFile -> the reference's loadBVH (staircase_scene.h:75-101): triangles, nodes, bounds and the leaf size come back byte for byte;
+    rtLoadBvhFile of the same file returns what loadBVH returns; both refuse a wrong header and a missing file."""
+    cases = [(rt.scene_staircase_procedural(1)[0], 5, None), (rt.scene_staircase_procedural(1)[0][:333], 3, 2)]
+    rng = np.random.default_rng(9)
+    soup = np.zeros(57, rt.triangle_dtype)
+    soup["v"] = rng.uniform(-3, 3, (57, 3, 3)).astype(np.float32)
+    soup["meshID"] = rng.integers(0, 20, 57)
+    cases.append((soup, 1, None))
+    for k, (tris, nppl, levels) in enumerate(cases):
+        hm = rt.HostMesh.build(tris, nppl, levels)
+        path = str(tmp_path / f"m{k}.bvh")
+        assert hm.save(path) == 0
+        got = O.ref_load_bvh(path)
+        assert got is not None
+        rtris, rbvh, rbounds, rnppl = got
+        assert rnppl == nppl == hm.nppl
+        assert rtris.tobytes() == hm.tris.tobytes() and rbvh.tobytes() == hm.bvh.tobytes()
+        assert rbounds.tobytes() == bytes(hm.view.bounds)
+        hm2 = rt.HostMesh.load(path)                                   # our reader on the same file: what the reference's reader returned
+        assert hm2.nppl == rnppl and hm2.tris.tobytes() == rtris.tobytes() and hm2.bvh.tobytes() == rbvh.tobytes()
+        assert bytes(hm2.view.bounds) == rbounds.tobytes()
+        if k == 0:
+            raw = open(path, "rb").read()
+            bad = str(tmp_path / "bad.bvh")
+            open(bad, "wb").write(b"BVH_00.03\x00" + raw[10:])
+            assert O.ref_load_bvh(bad) is None
+            with pytest.raises(ValueError):
+                rt.HostMesh.load(bad)
+        hm.close(); hm2.close()
+    assert O.ref_load_bvh(str(tmp_path / "missing.bvh")) is None
+
+
+def test_ppm_bytes_equal_the_reference_writer(rt, tmp_path):
+    """rtWritePPM's file = the bytes the reference's writePPM (staircase_scene.h:32-43) sends to std::cout: header, row order (top row first), sRGB
+    quantisation of every channel, separators - on random frames incl. negative, > 1, NaN-free extremes."""
+    rng = np.random.default_rng(11)
+    for (ny, nx) in ((1, 1), (7, 5), (33, 64)):
+        fb = rng.uniform(-0.2, 1.4, (ny, nx, 3)).astype(np.float32)
+        fb[0, 0] = (0.0, 1.0, 0.5)
+        if ny > 1:
+            fb[1, 0] = (1e-9, 1e9, 0.0031308)
+        path = str(tmp_path / "o.ppm")
+        assert rt.write_ppm(path, fb) == 0
+        assert open(path, "rb").read() == O.ref_write_ppm(fb)
+
+
+def test_staircase_camera_equals_the_reference_setup_camera(rt):
+    """rtStaircaseCamera = setup_camera (staircase_scene.h:62-73), every one of the 22 floats, for several image sizes."""
+    for (nx, ny) in ((640, 800), (1920, 1080), (160, 200), (48, 60), (1, 1), (1234, 567)):
+        assert bytes(rt.staircase_camera(nx, ny)) == bytes(O.ref_setup_camera(nx, ny)), (nx, ny)
+
+
+@pytest.mark.skipif(not O.have_ref_main(), reason="oracle/_ref/libref_main.so absent (built only where /root/reference exists)")
+def test_ref_files_against_the_reference_main_cpp(rt, tmp_path):
+    """REF_00.01 images (main.cpp:25-60): a file rtSaveReference writes loads through the reference's loadReference into the same floats, the file the
+    reference's saveReference writes is byte-identical to ours and loads through rtLoadReference; a size mismatch and a missing file are refused by both."""
+    rm = O.load_ref_main()
+    rng = np.random.default_rng(13)
+    nx, ny = 9, 6
+    fb = rng.uniform(0, 1.3, (ny, nx, 3)).astype(np.float32)
+    ours, theirs = str(tmp_path / "ours.ref"), str(tmp_path / "theirs.ref")
+    assert rt.save_reference(ours, fb) == 0
+    rm.ref_save_reference(theirs.encode(), nx, ny, fb.ctypes.data)
+    assert open(ours, "rb").read() == open(theirs, "rb").read()
+    back = np.zeros_like(fb)
+    assert rm.ref_load_reference(ours.encode(), back.ctypes.data, nx, ny) == 0 and back.tobytes() == fb.tobytes()
+    rc, back2 = rt.load_reference(theirs, nx, ny)
+    assert rc == 0 and back2.tobytes() == fb.tobytes()
+    assert rm.ref_load_reference(ours.encode(), back.ctypes.data, ny, nx) != 0 and rt.load_reference(ours, ny, nx)[0] != 0
+    assert rm.ref_load_reference(str(tmp_path / "none.ref").encode(), back.ctypes.data, nx, ny) != 0
+    bad = str(tmp_path / "bad.ref")
+    open(bad, "wb").write(b"REF_00.02\x00" + open(ours, "rb").read()[10:])
+    assert rm.ref_load_reference(bad.encode(), back.ctypes.data, nx, ny) != 0 and rt.load_reference(bad, nx, ny)[0] != 0
