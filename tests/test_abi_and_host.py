@@ -28,7 +28,7 @@ def test_renderer_exports_every_declared_symbol(rt):
         assert hasattr(lib, name), name
     assert set(rt.RENDERER_SYMBOLS) <= declared
     probe = re.findall(r"void (rtProbe[A-Za-z]+)##sfx", open(os.path.join(ROOT, "include", "rt_probe.h")).read())
-    assert len(probe) == 11
+    assert len(probe) == 12
     for base in probe:
         for sfx in ("_parity", "_fast"):
             assert hasattr(lib, base + sfx), base + sfx
