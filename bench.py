@@ -429,6 +429,9 @@ def main():
             j2 = run_job(hip, comm, WORKLOADS["C2"], max(args.steps, 5), 1, tag + "_c2")
             others["C2_partitioned"] = brief(j2, {"workload": WORKLOADS["C2"]["name"] + ", " + mode + f"; the fixed 1200x800 image over {world} GPUs",
                                                   "note": "strong scaling of a 16 ms frame: per-GPU kernel time is a few ms, the rest is launch, D2H and barrier"})
+            # the mesh / BVH path shards by the same stripes (tests/test_gpu_parity_mesh.py: the partition is invisible): C4 over the ranks
+            j4 = run_job(HipBackend(args.fp, "reference", 0), comm, WORKLOADS["C4"], 2, 1, tag + "_c4", count_spp=4, warmup_spp=16)
+            others["C4_partitioned"] = brief(j4, {"workload": WORKLOADS["C4"]["name"] + f", fp {args.fp}; the fixed 1920x1080 image over {world} GPUs"})
             # the same C5 frame on rank 0's GPU alone: this line's own strong-scaling denominator
             solo = None
             if rank == 0:

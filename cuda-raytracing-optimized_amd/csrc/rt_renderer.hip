@@ -91,7 +91,8 @@ struct RenderContext {
     rt_camera cam;
     rt_render_options opt;
     rt_vec3* h_fb = nullptr;            // pinned, nx*ny, handed to the caller
-    rt_vec3* h_ext = nullptr;           // caller-owned registered framebuffer (setExternalFramebuffer), or null
+    rt_vec3* h_ext = nullptr;           // caller-owned framebuffer (setExternalFramebuffer), or null
+    bool ext_registered = false;        // h_ext is page-locked and device-mapped (hipHostRegister succeeded): the kernels may store into it directly
     // host copies of the scene (so devices can be (re)configured by setRenderOptions)
     std::vector<float4> h_spheres;      // the kernel's sphere image (rt_params.h): (n_padded + n_groups) x (cx, cy, cz, r*r)
     std::vector<float> h_rad;           // n_padded radii
@@ -469,7 +470,7 @@ void cleanup_impl() {
     RenderContext& c = g_ctx;
     for (DeviceState& d : c.devs) free_device(d);
     c.devs.clear();
-    if (c.h_ext) { HIP_CHECK(hipHostUnregister(c.h_ext)); c.h_ext = nullptr; }
+    if (c.h_ext) { if (c.ext_registered) HIP_CHECK(hipHostUnregister(c.h_ext)); c.h_ext = nullptr; c.ext_registered = false; }
     if (c.h_fb) HIP_CHECK(hipHostFree(c.h_fb));
     c = RenderContext();
 }
@@ -661,7 +662,9 @@ void runRenderer(int ns, int tx, int ty) {
             if (want < ns) { spw = want; chunks = (ns + want - 1) / want; }
         }
         const int vk = c.opt.variant & 0xFF, vcb = (c.opt.variant >> 16) & 0xFF;
-        const bool fb_direct = c.is_spheres && c.max_depth > 0 && fb_direct_env && vk == 0 && (vcb == 0 || vcb == 255) && chunks == 1;
+        // (an external framebuffer that could not be page-locked is reached by the copy path only: see setExternalFramebuffer)
+        const bool fb_direct = c.is_spheres && c.max_depth > 0 && fb_direct_env && vk == 0 && (vcb == 0 || vcb == 255) && chunks == 1 &&
+                               (!c.h_ext || c.ext_registered);
         rt_vec3* const h_target = c.h_ext ? c.h_ext : c.h_fb;
         // Poison the framebuffer the kernel WRITES (all-ones = NaN): every pixel is written exactly once per frame, so a pixel the work
         // distribution lost shows up as NaN instead of as last frame's (correct-looking) value.  The compact device buffer is filled on the
@@ -813,9 +816,21 @@ void runRenderer(int ns, int tx, int ty) {
 void setExternalFramebuffer(rt_vec3* fb) {
     RenderContext& c = g_ctx;
     if (!c.initialised) rt_fail("setExternalFramebuffer before init");
-    if (c.h_ext) { HIP_CHECK(hipHostUnregister(c.h_ext)); c.h_ext = nullptr; }
+    if (c.h_ext) { if (c.ext_registered) HIP_CHECK(hipHostUnregister(c.h_ext)); c.h_ext = nullptr; c.ext_registered = false; }
     if (fb) {
-        HIP_CHECK(hipHostRegister(fb, (size_t)c.nx * c.ny * sizeof(rt_vec3), hipHostRegisterDefault));
+        // Page-locking the caller's memory (a /dev/shm mapping shared by the ranks of a node, bench.py) lets the kernels deliver finished pixels
+        // straight into it.  If the runtime refuses (locked-memory limit of the account, a mapping it cannot pin) the job must not die on its first
+        // multi-GPU node: the renderer falls back to its compact device buffer and plain device-to-host copies of this member's stripes into the
+        // (pageable) memory - slower by the copy, same image.  RT_EXT_FB_NO_REGISTER=1 forces that path (tests).
+        const char* no_reg = getenv("RT_EXT_FB_NO_REGISTER");
+        hipError_t e = (no_reg && no_reg[0] == '1') ? hipErrorNotSupported
+                                                    : hipHostRegister(fb, (size_t)c.nx * c.ny * sizeof(rt_vec3), hipHostRegisterDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();                                 // (clear the sticky error: it has been handled)
+            fprintf(stderr, "rt warning: setExternalFramebuffer could not page-lock the caller's framebuffer (%s): stripes are copied into it "
+                            "from the device buffer instead of being stored by the kernel\n", hipGetErrorString(e));
+        }
+        c.ext_registered = e == hipSuccess;
         c.h_ext = fb;
     }
 }

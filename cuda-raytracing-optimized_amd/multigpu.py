@@ -62,15 +62,22 @@ class ShmComm:
     """barrier() and reduce(values, "max" | "sum") over the ranks of ONE node through a small file in /dev/shm: no RCCL, no sockets.
 
     Layout: a 64-byte header (magic, world) and one 4 KB slot per rank: slot[0] = the rank's barrier generation, slot[1] = number of values,
-    slot[2..] = its float64 values.  Every word has exactly one writer (its rank), so no atomic read-modify-write is needed: a barrier is
-    "bump my generation, wait until every rank's generation has reached mine".  The name carries MASTER_PORT and the parent process id,
+    slot[2..] = its float64 values, slot[511] = its process id.  Every word has exactly one writer (its rank), so no atomic read-modify-write is
+    needed: a barrier is "bump my generation, wait until every rank's generation has reached mine".  A rank that waits checks twice a second that
+    the ranks it waits for are still alive (the pid in their slot: gone, or a zombie, means the rank died - the renderer ends the process on a HIP
+    error, kernels.cu:27-38 - and no generation will ever come): it raises PeerDied at once instead of sitting out the timeout, so that the job ends
+    non-zero with a message whatever the launcher does about the other ranks.  The timeout (480 s) stays below the driver's 600 s limit for a bench run.  The name carries MASTER_PORT and the parent process id,
     which the ranks of one launch share (torch.distributed.run's agent, or the test's spawning process), so a launch never attaches to the
     file of another one; rank 0 creates the file under a temporary name and renames it into place, the others wait for it."""
 
     MAGIC = 0x52544D4D          # "RTMM"
     SLOT = 4096
+    PID_WORD = 511
 
-    def __init__(self, rank, world, tag=None, timeout=900.0):
+    class PeerDied(RuntimeError):
+        pass
+
+    def __init__(self, rank, world, tag=None, timeout=480.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         tag = tag if tag is not None else f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         self.path = f"/dev/shm/rt_comm_{tag}.bin"
@@ -99,27 +106,54 @@ class ShmComm:
         if magic != self.MAGIC or w != self.world:
             raise RuntimeError(f"ShmComm: {self.path} belongs to another job (magic {magic:#x}, world {w})")
         self.slots = [self.mm[64 + self.SLOT * r:64 + self.SLOT * (r + 1)].view(np.float64) for r in range(self.world)]
+        self.slots[self.rank][self.PID_WORD] = float(os.getpid())
         self.gen = 0
         self.barrier()
+
+    @staticmethod
+    def _alive(pid):
+        """False when the process is gone or a zombie (exited, not yet reaped by its launcher)."""
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        try:
+            with open(f"/proc/{pid}/stat", "rb") as f:
+                return f.read().rsplit(b")", 1)[1].split()[0] != b"Z"
+        except OSError:
+            return True
+
+    def _check_peers(self, behind):
+        for r in behind:
+            pid = int(self.slots[r][self.PID_WORD])
+            if pid > 0 and not self._alive(pid):
+                raise ShmComm.PeerDied(f"ShmComm: rank {r} (pid {pid}) died before barrier {self.gen}; rank {self.rank} gives up")
 
     def barrier(self):
         self.gen += 1
         self.slots[self.rank][0] = float(self.gen)
         t0 = time.monotonic()
         spins = 0
+        next_check = t0 + 0.5
         while True:
             if all(s[0] >= self.gen for s in self.slots):
                 return
             spins += 1
             if spins > 2000:                                    # a rank that renders for seconds: stop burning a core
                 time.sleep(0.0002)
-            if time.monotonic() - t0 > self.timeout:
-                behind = [r for r, s in enumerate(self.slots) if s[0] < self.gen]
-                raise TimeoutError(f"ShmComm: barrier {self.gen} timed out after {self.timeout} s waiting for ranks {behind}")
+                now = time.monotonic()
+                if now >= next_check:
+                    next_check = now + 0.5
+                    behind = [r for r, s in enumerate(self.slots) if s[0] < self.gen]
+                    self._check_peers(behind)
+                    if now - t0 > self.timeout:
+                        raise TimeoutError(f"ShmComm: barrier {self.gen} timed out after {self.timeout} s waiting for ranks {behind}")
 
     def reduce(self, values, op):
         vals = [float(v) for v in values]
-        assert len(vals) <= self.SLOT // 8 - 2
+        assert len(vals) <= self.PID_WORD - 2
         mine = self.slots[self.rank]
         mine[1] = float(len(vals))
         mine[2:2 + len(vals)] = vals
@@ -133,6 +167,8 @@ class ShmComm:
     def close(self):
         try:
             self.barrier()
+        except (TimeoutError, ShmComm.PeerDied):
+            pass                                                # (a dead peer was reported where it was first seen)
         finally:
             self.slots = None
             self.mm = None

@@ -55,7 +55,9 @@ void setRenderOptions(const rt_render_options* opt);
 /* Makes the following runRenderer calls deliver into caller-owned host memory (nx*ny vec3) instead of the
  * library's own framebuffer: the buffer is page-locked with hipHostRegister and becomes the target of the
  * device-to-host stripe copies.  Used for the multi-process host gather: every rank passes the same shared
- * mapping and writes only the stripes it owns.  NULL switches back.  The caller keeps ownership. */
+ * mapping and writes only the stripes it owns.  NULL switches back.  The caller keeps ownership.
+ * If the runtime cannot page-lock the memory, a warning is printed and the stripes are copied into it as pageable
+ * memory (same image, no direct delivery by the kernel): never a reason to exit. */
 void setExternalFramebuffer(rt_vec3* fb);
 
 /* Timing / counters of the last runRenderer. */

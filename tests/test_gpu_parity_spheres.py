@@ -363,6 +363,36 @@ def test_external_framebuffer(rt, O, tmp_path):
     rt.cleanupRenderer()
 
 
+def test_external_framebuffer_that_cannot_be_page_locked(rt, O, tmp_path, capfd):
+    """setExternalFramebuffer when hipHostRegister refuses the caller's memory (forced: RT_EXT_FB_NO_REGISTER=1; on a node: a locked-memory limit): a
+    warning, and the renderer copies this member's stripes from its compact device buffer into the pageable memory instead of exiting - the same image,
+    on the two-dispatch frame (ns = 8) and on the single dispatch (ns = 2), for every member of a 3-way partition."""
+    import os
+    nx, ny = 120, 72
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    path = str(tmp_path / "fb.npy")
+    np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(ny, nx, 3)).flush()
+    ext = np.load(path, mmap_mode="r+")
+    fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, 50)
+    os.environ["RT_EXT_FB_NO_REGISTER"] = "1"
+    try:
+        rt.setExternalFramebuffer(ext)
+    finally:
+        del os.environ["RT_EXT_FB_NO_REGISTER"]
+    assert "could not page-lock" in capfd.readouterr().err
+    o = rt.getDefaultRenderOptions(True)
+    for ns in (8, 2):
+        ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50)
+        ext[:] = 0
+        for r in range(3):
+            rt.setRenderOptions(o, part_rank=r, part_world=3)
+            rt.runRenderer(ns, 8, 8)
+        assert np.array_equal(_bits(np.array(ext)), _bits(ref)), ns
+    assert not np.array(fb).any()
+    rt.setExternalFramebuffer(None)
+    rt.cleanupRenderer()
+
+
 def test_config5_image_size_crops(rt, O):
     """BASELINE config-5 geometry (3840x2160, 488 spheres) at 1 spp on one GPU: the oracle checks four 24x16 crops,
     and the frame must be complete (a pixel is black only when its single path ran into maxDepth inside glass:

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 3 (gloo): the N>1 path of bench.py.  The workers call bench.run_job() — THE partitioned job
+"""CPU, world_size 2, 3, 4 and 8 (gloo and /dev/shm): the N>1 path of bench.py.  The workers call bench.run_job() — THE partitioned job
 of the benchmark: stripe partition, framebuffer shared by the ranks, barrier-bracketed timing, max / sum over ranks
 through bench.DistComm — with a backend that renders the rank's stripes with the CPU oracle (test infrastructure
 standing in for the GPU, which this container does not have; on the GPU box the backend is bench.HipBackend).
@@ -87,7 +87,7 @@ def _worker(rank, world, port, w, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nx,ny", [(2, 64, 44), (3, 40, 64)])
+@pytest.mark.parametrize("world,nx,ny", [(2, 64, 44), (3, 40, 64), (8, 40, 136)])
 def test_bench_run_job_partitions_and_gathers_the_single_process_image(tmp_path, world, nx, ny, rt, O):
     w = dict(kind="spheres", nx=nx, ny=ny, spp=2, depth=50, name="test")
     out = str(tmp_path / "fb.npy")
@@ -119,7 +119,7 @@ def _shm_worker(rank, world, port, w, out_path):
     comm.close()
 
 
-@pytest.mark.parametrize("world,nx,ny", [(2, 64, 44), (4, 48, 72)])
+@pytest.mark.parametrize("world,nx,ny", [(2, 64, 44), (4, 48, 72), (8, 40, 136)])
 def test_bench_run_job_over_the_shm_barrier(tmp_path, world, nx, ny, rt, O):
     """bench.py --gpus N as the driver launches it uses no RCCL at all: the framebuffer is gathered on the host and the barrier / reductions
     of the timing go through a /dev/shm file.  Same job, same checks as the gloo variant above, plus bench.verify_gather()."""
@@ -145,6 +145,43 @@ def test_bench_run_job_over_the_shm_barrier(tmp_path, world, nx, ny, rt, O):
     broken = got.copy()
     broken[0, 0, 0] = np.nan                              # a lost pixel (the renderer poisons the framebuffer with NaN before each frame)
     assert bench.verify_gather(broken, broken, world)["gather_ok"] is False
+
+
+def _dying_worker(rank, world, port, ppid_tag):
+    """Rank `world - 1` dies (as the renderer does on a HIP error: exit(99)) after the first barrier; the others must notice within seconds."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    from cuda_raytracing_optimized_amd import multigpu
+    comm = multigpu.ShmComm(rank, world, tag=ppid_tag, timeout=60.0)
+    comm.barrier()
+    if rank == world - 1:
+        os._exit(99)
+    t0 = time.monotonic()
+    try:
+        comm.reduce([1.0], "sum")
+    except multigpu.ShmComm.PeerDied as e:
+        assert f"rank {world - 1}" in str(e) and time.monotonic() - t0 < 10.0
+        comm.close()                                    # must not hang either
+        os._exit(7)
+    os._exit(0)
+
+
+def test_a_dead_rank_ends_the_job_with_a_message_not_a_timeout():
+    """a rank that dies inside the job (rt_fail -> exit(99)) left the others in a 900 s barrier.  Now every waiting rank checks the pids
+    of the ranks it waits for: PeerDied within a second, a non-zero exit of every rank, nothing left in /dev/shm."""
+    import time
+    ctx = mp.get_context("spawn")
+    world, tag = 3, f"dying_{os.getpid()}"
+    t0 = time.monotonic()
+    procs = [ctx.Process(target=_dying_worker, args=(r, world, 0, tag)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert [p.exitcode for p in procs] == [7, 7, 99]
+    assert time.monotonic() - t0 < 45.0
+    assert not [f for f in os.listdir("/dev/shm") if f == f"rt_comm_{tag}.bin"]
 
 
 def test_run_job_single_rank_needs_no_shared_framebuffer(rt, O):

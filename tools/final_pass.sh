@@ -10,6 +10,6 @@ python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_parity.json 2> $O/${TAG
 python3 bench.py --no-cpu-baseline --fp fast > $O/${TAG}_bench_fpfast.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --rng counter > $O/${TAG}_bench_rngcounter.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --fp fast --rng counter > $O/${TAG}_bench_fpfastrngcounter.json 2>/dev/null
-HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > $O/${TAG}_bench_n2_rehearsal.json 2> $O/${TAG}_bench_n2_rehearsal.err
+env -u HSA_ENABLE_IPC_MODE_LEGACY timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > $O/${TAG}_bench_n2_rehearsal.json 2> $O/${TAG}_bench_n2_rehearsal.err
 cat $O/${TAG}_bench_parity.json $O/${TAG}_bench_fpfast.json $O/${TAG}_bench_rngcounter.json $O/${TAG}_bench_fpfastrngcounter.json | python3 tools/brief.py
 tail -c 600 $O/${TAG}_bench_n2_rehearsal.json
