@@ -190,8 +190,39 @@ __device__ __forceinline__ bool fresnel_layer(f3 normal, bool inside, f3 wo, flo
 // material_scatter, scene_materials.h:13-20, with the BSDFs of material.h.  `normal` faces the ray; `inside` is the
 // path's inside flag; `wo` the un-renormalised path direction; `hp` the hit point (only the checker preset reads it).
 // type >= RT_FLOOR_COAT selects one of the reference's dormant look presets (scene_materials.h:22-93; additive).
+// BASIC (the sphere kernel's instantiation for scenes whose materials are all RT_DIFFUSE / RT_METAL / RT_GLASS - every scene of the README-era renderer): the
+// same three BSDFs without the presets' parameter tables, layers, absorption and subsurface events around them - the same operations on the same operands,
+// so the same bits (1.0f * tint is tint), in a third of the code and registers.
+template <bool BASIC = false>
 __device__ __forceinline__ void material_scatter(Scatter& out, float hit_t, f3 hp, f3 normal, bool inside, f3 wo,
                                                  int type, f3 color, float param, uint32_t& rng) {
+    if (BASIC) {
+        const bool diffuse = type == RT_DIFFUSE, metal = type == RT_METAL;
+        bool fresnel = false;
+        if (!diffuse && !metal) fresnel = fresnel_layer(normal, inside, wo, param, rng);        // dielectric_bsdf, material.h:73-92
+        f3 rs = F3(0, 0, 0);
+        if (diffuse || (metal && param > 0.0001f)) rs = random_in_unit_sphere(rng);
+        f3 v, thr = color;
+        bool refracted = false;
+        if (diffuse) {                                           // diffuse_bsdf, material.h:27-31
+            v = normal + rs;
+        } else if (metal) {                                      // glossy_bsdf, material.h:46-53
+            v = reflect(wo, normal);
+            if (param > 0.0001f) v = v + param * rs;
+        } else if (fresnel) {
+            v = reflect(wo, normal);                             // glossy_bsdf, fuzz 0; throughput (1, 1, 1) * tint
+        } else {
+            v = refract(wo, normal, inside ? param : (1.0f / param));
+            refracted = true;
+            thr = F3(1.0f, 1.0f, 1.0f);
+        }
+        out.wi = unit(v);
+        out.throughput = thr;
+        out.specular = !diffuse;
+        out.refracted = refracted;
+        out.t = hit_t;
+        return;
+    }
     // Every branch is reduced to: an un-normalised outgoing direction v (normalised once at the end, except for the
     // subsurface scattering event which the reference leaves un-normalised, material.h:128), a throughput, flags and t.
     // (Written per branch as `out.throughput = out.throughput * color`, hipcc 7.2 dropped the x component of the

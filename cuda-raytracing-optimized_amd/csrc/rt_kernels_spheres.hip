@@ -57,6 +57,10 @@ using namespace rtd;
 
 namespace {
 
+#ifndef RT_BOX_CUT
+#define RT_BOX_CUT 12       // group_needs_cells: the per-lane box loop stops when fewer lanes than this still have candidates (A/B on C5 at 256 spp, profiles/r04_ab_basic_c5.txt:
+                            // off 10870, 8: 10930, 12: 10945, 20: 10945 Msamples/s)
+#endif
 constexpr int kWavesPerWg = 16;             // 16 waves - a whole CU at 4 waves per SIMD - share ONE LDS copy of the scene (tile kernel: 16 tiles side by side)
 constexpr int kThreads = 64 * kWavesPerWg;
 
@@ -434,6 +438,25 @@ __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, c
         return __float_as_uint(t_out - t_in);
     };
     uint32_t need = 0;
+#if RT_BOX_CUT > 0
+    // The loop below is per lane: the wave runs it as long as its lane with the most candidates needs (a grazing ray that lies long in the slab), two box
+    // tests per step.  A step that serves only a few lanes costs the wave more than it can save: an untested candidate simply becomes a (ray, group) pair -
+    // 16 sphere pre-tests on ONE lane of a pair round, the culling being an optimisation, never part of the result.  So the loop ends when fewer than
+    // RT_BOX_CUT lanes still have candidates, and what they have left is taken untested.
+    while (__popcll(__ballot(cand != 0u)) >= RT_BOX_CUT) {
+        if (cand != 0u) {
+            const int ga = __builtin_ctz(cand);
+            cand &= cand - 1u;
+            const int gb = cand != 0u ? __builtin_ctz(cand) : ga;
+            cand &= cand - 1u;
+            const f2u a1 = *reinterpret_cast<const f2u*>(f1 + 12 * ga), a2 = *reinterpret_cast<const f2u*>(f2 + 12 * ga);
+            const f2u b1 = *reinterpret_cast<const f2u*>(f1 + 12 * gb), b2 = *reinterpret_cast<const f2u*>(f2 + 12 * gb);
+            need |= ((~gap(a1, a2)) >> 31) << ga;
+            need |= ((~gap(b1, b2)) >> 31) << gb;
+        }
+    }
+    return need | cand;
+#endif
     while (cand != 0u) {                                             // (per lane: the wave runs max-over-lanes / 2 steps)
         const int ga = __builtin_ctz(cand);
         cand &= cand - 1u;
@@ -903,7 +926,7 @@ __device__ __forceinline__ Hit scan_single(const RtSphereParams& P, const SceneL
 template <bool STATS>
 __device__ __forceinline__ void ray_stat(const RtSphereParams& P, int k) { if (STATS && P.counters) atomicAdd(&P.counters->ref_stats[k], 1ull); }
 
-template <bool STATS>
+template <bool STATS, bool BASIC = false>
 __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S, Lane& L, f3 dn, Hit h) {
     const bool primary = L.bounce == 0;
     if (STATS && P.counters) {                                       // kernels.cu:403-408
@@ -924,7 +947,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
     if (dot(dn, normal) > 0.0f) normal = -normal;                    // kernels.cu:354-355
     const float4 m = S.mat[h.sid];
     Scatter sc;
-    material_scatter(sc, h.closest, hp, normal, L.inside, L.dir, S.typ[h.sid], F3(m.x, m.y, m.z), m.w, L.rng);
+    material_scatter<BASIC>(sc, h.closest, hp, normal, L.inside, L.dir, S.typ[h.sid], F3(m.x, m.y, m.z), m.w, L.rng);
     L.org = L.org + sc.t * L.dir;                                    // kernels.cu:485-489
     L.dir = sc.wi;
     L.atten = L.atten * sc.throughput;
@@ -949,7 +972,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // lanes must call it together.  With many live lanes each lane scans the sphere list for its own ray; with few
 // (the tail of a tile / of the frame, where a handful of pixels in sphere / ground wedges need thousands of rays each) the
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
-template <bool LEGACY, bool STATS = false>
+template <bool LEGACY, bool STATS = false, bool BASIC = false>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
                                            uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
@@ -984,7 +1007,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
         }
     }
     bool done = false;
-    if (has_ray) done = shade<STATS>(P, S, L, dn, h);
+    if (has_ray) done = shade<STATS, BASIC>(P, S, L, dn, h);
     lap(5);
     return done;
 }
@@ -1244,7 +1267,8 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists; 28..31 pixels a
 // chain wave holds while one of them comes from list 0 (the longest chains).
 //   SCENE    where the scene is read from (stage_scene): 0 = an LDS copy, 1 = global memory, 2 = test data in the LDS, hit data in global memory
-template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0>
+//   BASIC    the scene's materials are the three basic ones: lean shading (material_scatter<BASIC>); only with SCENE = 0 and without DBG
+template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0, bool BASIC = false>
 __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
@@ -1543,7 +1567,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             }
             if (sel) { nrays++; pix_rays++; }
             if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            const bool done = trace_rays<false, DBG>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
+            const bool done = trace_rays<false, DBG, BASIC>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
             if (dbg_timers) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel, steps > 1);
         }
@@ -1639,7 +1663,16 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    static const bool basic_env = !(getenv("RT_BASIC") && getenv("RT_BASIC")[0] == '0');       // A/B: RT_BASIC=0 keeps the general shading code
     if (counting) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
+    else if (SCENE == 0 && q.basic_materials && basic_env) {
+        const void* kb = reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, true>);
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, true>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
+    }
     else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
     return hipGetLastError();
 }

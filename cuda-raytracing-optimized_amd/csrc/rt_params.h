@@ -52,6 +52,7 @@ struct RtSphereParams {
     const float*  rad;          // n_padded: radius of slot k (the hit normal divides by it, intersections.h:95)
     int32_t fb_global_rows;     // 1 = `fb` is the WHOLE image (the pinned host framebuffer, written over the bus as pixels finish): rows are global, not local
     const struct RtSphereParams* self;   // a device copy of this struct (launcher): the kernel re-reads what it needs once per sample / pixel from it
+    int32_t basic_materials;    // 1 = every material is RT_DIFFUSE, RT_METAL or RT_GLASS (no look preset): the lean shading instantiation may run (material_scatter<BASIC>)
     int32_t global_scene;       // 1 = the scene does not fit the LDS: the kernels read these arrays from global memory (L2) instead of staging them
     const float4* groups;       // 2 x n_groups: inflated AABB (lo.xyz, hi.xyz) of each group
     // per-ray culling margin (exactness of the culling for ANY ray origin, see make_box_ray): centre and radius of the

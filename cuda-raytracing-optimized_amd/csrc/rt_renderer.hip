@@ -97,6 +97,7 @@ struct RenderContext {
     std::vector<float4> h_spheres;      // the kernel's sphere image (rt_params.h): (n_padded + n_groups) x (cx, cy, cz, r*r)
     std::vector<float> h_rad;           // n_padded radii
     int global_scene = 0;
+    int basic_materials = 0;            // every material is RT_DIFFUSE / RT_METAL / RT_GLASS (RtSphereParams::basic_materials)
     std::vector<float4> h_mat_color;
     std::vector<int32_t> h_mat_type;
     std::vector<float4> h_groups;       // three float4 per group of kSphereGroup slots: per axis (lo, hi, lo, -) of the tight AABB
@@ -351,6 +352,8 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     // bounds: 3 float4 per group, one per AXIS: (lo, hi, lo, -) - a ray reads two consecutive floats, at 0 or at 1 by the sign of its direction,
     // and has (near plane, far plane).  Empty group: lo > hi on every axis (never reachable).
     c.h_groups.assign((size_t)c.n_groups * 3, make_float4(3.0e38f, -3.0e38f, 3.0e38f, 0.0f));
+    c.basic_materials = 1;
+    for (int k = 0; k < n; k++) if (materials[k].type != RT_DIFFUSE && materials[k].type != RT_METAL && materials[k].type != RT_GLASS) c.basic_materials = 0;
     for (int s = 0; s < c.n_padded; s++) {
         const int k = slots[s];
         if (k < 0) continue;
@@ -680,7 +683,7 @@ void runRenderer(int ns, int tx, int ty) {
             memset(&p, 0, sizeof p);
             p.cam = c.cam; p.nx = c.nx; p.ny = c.ny; p.ns = ns; p.max_depth = c.max_depth;
             p.n = c.n_spheres; p.n_padded = c.n_padded; p.n_groups = c.n_groups; p.n_big_groups = c.n_big_groups; p.n_big = c.n_big;
-            p.spheres = d.d_spheres; p.rad = d.d_rad; p.global_scene = c.global_scene; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
+            p.spheres = d.d_spheres; p.rad = d.d_rad; p.global_scene = c.global_scene; p.basic_materials = c.basic_materials; p.mat_color = d.d_mat_color; p.mat_type = d.d_mat_type;
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
             p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max; p.pair_k0 = c.pair_k0; p.box_shared_axis = c.box_shared_axis; p.box_shared_lo = c.box_shared_lo; p.box_shared_hi = c.box_shared_hi;
