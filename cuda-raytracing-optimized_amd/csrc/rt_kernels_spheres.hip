@@ -65,10 +65,17 @@ constexpr int kWavesPerWg = 16;             // 16 waves - a whole CU at 4 waves 
 constexpr int kThreads = 64 * kWavesPerWg;
 
 constexpr int kPassGroups = 16;
-constexpr int kListCap = 64 * 16 + 64;
 constexpr int kCandCap = 192;
-constexpr int kWaveScratchPairs = 64 * 32 + 64 * 8 + (64 * kPassGroups + 64) * 2;
-constexpr int kWaveScratch = kWaveScratchPairs + kCandCap * 4 + 16;
+__host__ __device__ constexpr int ws_cand_cap(bool onepass) { return onepass ? 128 : kCandCap; }
+// Per-wave scratch: ray table (64 x 32 B), best-hit keys (64 x 8 B), the (ray, group) pair list (2 B per entry), the candidate list.  The pair list holds one pass
+// of kPassGroups groups for every lane + the carried remainder; the one-pass kernels (scan_pairs<ONEPASS>: 32 groups behind the prefilter, ~70 pairs per ray batch)
+// keep a list of 8 groups per lane + remainder - a batch that would overflow it is cut into quarters (wave-uniform, not seen on the benchmark) - which is
+// what lets two 10-wave workgroups with a scene copy each share a CU's LDS (5 waves per SIMD).
+__host__ __device__ constexpr int ws_list_cap(bool onepass) { return onepass ? 64 * 8 + 64 : 64 * kPassGroups + 64; }
+__host__ __device__ constexpr int ws_pairs(bool onepass) { return 64 * 32 + 64 * 8 + ws_list_cap(onepass) * 2; }
+__host__ __device__ constexpr int ws_total(bool onepass) { return ws_pairs(onepass) + ws_cand_cap(onepass) * 4 + 16; }
+constexpr int kListCap = ws_list_cap(false);
+constexpr int kWaveScratch = ws_total(false);
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
     const int stripe = lr / pt.stripe_rows;
@@ -506,19 +513,22 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {
 //    reference's first-index-wins closest hit).
 // The work a wave does is proportional to the pairs that exist, not to 64 x (union of groups): incoherent waves do not
 // pay for each other's groups, and a wave with few live rays uses all 64 lanes on them.  WAVE-LEVEL: all 64 lanes call it.
+// ONEPASS (the launcher's promise: culling on, cell tables on, at most 32 small groups - the benchmark scene and everything of its size): the pass loop below
+// runs exactly once with every pass-level decision known at compile time (no windows, no carry between passes, no choice of the box test).
+template <bool ONEPASS = false>
 __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, bool has_ray, bool cull,
                                           uint32_t& groups_done, uint32_t& boxes_done, unsigned long long* tm = nullptr) {
     // tm (diagnostic instantiation only): cycles in [1] big spheres, [2] group boxes + pair list, [3] pair rounds, [4] candidates
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
-    unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
+    unsigned char* W = S.scratch + (threadIdx.x >> 6) * ws_total(ONEPASS);
     float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r: (origin, a) at w_ray[r], (direction, -) at w_ray[64 + r] - two arrays of 16-byte
                                                                                 // entries: the pair lanes of a round fetch rays of (mostly) consecutive owners, and 16
                                                                                 // consecutive 16-byte entries cover all 64 banks once (32-byte entries: twice)
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);
-    uint32_t* w_cand = reinterpret_cast<uint32_t*>(W + kWaveScratchPairs);
+    uint32_t* w_cand = reinterpret_cast<uint32_t*>(W + ws_pairs(ONEPASS));
     const float t_min = P.t_min;
     uint32_t n_c = 0;                                                // wave-uniform: candidates in the list (a register: the list is this wave's own)
 
@@ -550,9 +560,9 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
             if (m == 0ull) break;
             if (bits != 0u) {
                 const uint32_t pos = n_c + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pos < (uint32_t)kCandCap) w_cand[pos] = entry_of(bits);     // (a full list leaves the candidate in `bits`)
+                if (pos < (uint32_t)ws_cand_cap(ONEPASS)) w_cand[pos] = entry_of(bits);     // (a full list leaves the candidate in `bits`)
             }
-            n_c = min(n_c + (uint32_t)__popcll(m), (uint32_t)kCandCap);
+            n_c = min(n_c + (uint32_t)__popcll(m), (uint32_t)ws_cand_cap(ONEPASS));
         }
         while (bits != 0u) resolve(entry_of(bits));                  // more than kLevels candidates in one lane, or the list is full (never seen on C2): in place
     };
@@ -605,17 +615,16 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     int carry = 0;                                                   // wave-uniform: pairs already in the list
     int win_base = P.n_big_groups;                                   // entries hold lane << 10 | (group - win_base): a window of 1024 groups
     // A scene of up to 32 small groups (the benchmark: 31) takes ONE pass of 32: one prefix sum, one list write, one synchronisation per ray batch instead of
-    // two.  The list holds 64 x 16 + 64 entries; a pass of 32 whose pairs would not fit (every ray reaching more than half of the scene: not seen) is
-    // split into its two halves of 16 groups (wave-uniform), like the passes of larger scenes.
-    const int pass_w = (P.n_groups - P.n_big_groups <= 32 || (cull && P.cell_on != 0)) ? 32 : kPassGroups;
+    // two.  A pass of 32 whose pairs would not fit the list (every ray reaching a good part of the scene: not seen) is split into quarters of 8 groups (wave-uniform).
+    const int pass_w = (ONEPASS || P.n_groups - P.n_big_groups <= 32 || (cull && P.cell_on != 0)) ? 32 : kPassGroups;
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += pass_w) {
-        const int ng = min(pass_w, P.n_groups - g0);
+        const int ng = ONEPASS ? P.n_groups - g0 : min(pass_w, P.n_groups - g0);
         // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
-        const bool flush = g0 + 2 * pass_w - win_base > 1024;
-        const bool last_pass = g0 + pass_w >= P.n_groups || flush;
+        const bool flush = !ONEPASS && g0 + 2 * pass_w - win_base > 1024;
+        const bool last_pass = ONEPASS || g0 + pass_w >= P.n_groups || flush;
         uint32_t need_all = 0u;
         if (has_ray) {
-            if (cull && P.cell_on != 0) {                            // (passes of 32 groups, pass k = word k of the cell sets; shared axis y)
+            if (ONEPASS || (cull && P.cell_on != 0)) {               // (passes of 32 groups, pass k = word k of the cell sets; shared axis y)
                 need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done, (g0 - P.n_big_groups) >> 5);
             } else {
                 need_all = group_needs(P, S, g0, ng, br, cull);
@@ -625,11 +634,12 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         // exclusive prefix sum of the pair counts over the wave
         const int cnt_all = __popc(need_all);
         const int incl_all = wave_inclusive_scan(cnt_all);
-        const bool split = carry + __builtin_amdgcn_readlane(incl_all, 63) > kListCap;       // (pass_w = 32 only)
-      for (int half = 0; half < (split ? 2 : 1); half++) {
-        const uint32_t need = split ? (half ? need_all >> 16 : (need_all & 0xFFFFu)) : need_all;
-        const int sg0 = g0 + (split ? 16 * half : 0);
-        const bool last_sub = last_pass && (!split || half == 1);
+        // a pass of 32 whose pairs would not fit the list is cut into quarters of 8 groups (64 x 8 + the carried remainder always fit)
+        const bool split = pass_w == 32 && carry + __builtin_amdgcn_readlane(incl_all, 63) > ws_list_cap(ONEPASS);
+      for (int half = 0; half < (split ? 4 : 1); half++) {
+        const uint32_t need = split ? ((need_all >> (8 * half)) & 0xFFu) : need_all;
+        const int sg0 = g0 + (split ? 8 * half : 0);
+        const bool last_sub = last_pass && (!split || half == 3);
         const int cnt = split ? __popc(need) : cnt_all;
         const int incl = split ? wave_inclusive_scan(cnt) : incl_all;
         const int total = carry + __builtin_amdgcn_readlane(incl, 63);
@@ -707,7 +717,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         // carry the remainder to the front of the list (nothing to move when no round ran - the common first pass of a 31-group scene: its ~35 pairs
         // already sit at the front - or when nothing is left)
         carry = total - stop;
-        if (stop > 0 && carry > 0) {
+        if (!ONEPASS && stop > 0 && carry > 0) {
             unsigned short moved = 0;
             if (lane < carry) moved = w_pair[stop + lane];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -718,6 +728,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         }
       }
         if (flush) win_base = g0 + pass_w;                           // (the list is empty here)
+        if (ONEPASS) break;
     }
     {                                                                // the candidates left over
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (big-sphere candidates when no pair round ran)
@@ -770,20 +781,22 @@ __device__ __forceinline__ void sparse_test_slot(const RtSphereParams& P, const 
 // (reachable (ray, group) pair, sphere of the group) - are numbered across the rays and dealt to the 64 lanes, 64 at a time;
 // a lane fetches the ray of its item from the wave's LDS ray table.  Two rays therefore cost three lane passes like one
 // ray does (16 + 16 big slots, 31 + 31 boxes, ~2 x 16 spheres), where handling the rays one after the other cost six.
+template <bool ONEPASS = false>
 __device__ __forceinline__ Hit scan_sparse(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, unsigned long long live,
                                            bool cull, unsigned long long* tm = nullptr) {
     // tm (diagnostic instantiation only): cycles in [10] ray table + box set-up, [11] big spheres, [12] group boxes, [13] sphere tests + read-back
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
-    unsigned char* W = S.scratch + (threadIdx.x >> 6) * kWaveScratch;
+    unsigned char* W = S.scratch + (threadIdx.x >> 6) * ws_total(ONEPASS);
     float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r at w_ray[r], w_ray[64 + r] (as in scan_pairs)
     unsigned long long* w_best = reinterpret_cast<unsigned long long*>(W + 64 * 32);   // best key of ray r at w_best[r]
     unsigned short* w_pair = reinterpret_cast<unsigned short*>(W + 64 * 32 + 64 * 8);  // reachable (ray << 12 | group) pairs
     const bool mine = ((live >> lane) & 1ull) != 0ull;
     const int m = (int)__popcll(live);                               // rays (wave-uniform)
     const int my_r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-    float4* w_box = reinterpret_cast<float4*>(W + kWaveScratchPairs);           // the ray side of the box tests, 3 float4 per ray (<= 16 rays: the candidate list's space)
+    float4* w_box = w_ray + 16;                                                 // the ray side of the box tests, 3 float4 per ray: <= 16 rays use entries [0, 16) and [64, 80) of the
+                                                                                // ray table, so its entries [16, 64) are free
     if (mine) {
         w_ray[my_r] = make_float4(org.x, org.y, org.z, a);
         w_ray[64 + my_r] = make_float4(dn.x, dn.y, dn.z, 0.0f);
@@ -972,7 +985,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // lanes must call it together.  With many live lanes each lane scans the sphere list for its own ray; with few
 // (the tail of a tile / of the frame, where a handful of pixels in sphere / ground wedges need thousands of rays each) the
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
-template <bool LEGACY, bool STATS = false, bool BASIC = false>
+template <bool LEGACY, bool STATS = false, bool BASIC = false, bool ONEPASS = false>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
                                            uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
@@ -991,9 +1004,10 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
             if (has_ray) h = hq;
             if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[6] += n_ - tc; tc = n_; }
         } else
-        if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && P.n_groups <= 4096 &&
-            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap) { h = scan_sparse(P, S, L.org, dn, a, live, cull, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
-        else { h = scan_pairs(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
+        // (ONEPASS: at most 16 rays x 32 groups = 512 entries: always fits)
+        if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && (ONEPASS || (P.n_groups <= 4096 &&
+            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap))) { h = scan_sparse<ONEPASS>(P, S, L.org, dn, a, live, cull, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
+        else { h = scan_pairs<ONEPASS>(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
     } else {
@@ -1267,9 +1281,11 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists; 28..31 pixels a
 // chain wave holds while one of them comes from list 0 (the longest chains).
 //   SCENE    where the scene is read from (stage_scene): 0 = an LDS copy, 1 = global memory, 2 = test data in the LDS, hit data in global memory
-//   BASIC    the scene's materials are the three basic ones: lean shading (material_scatter<BASIC>); only with SCENE = 0 and without DBG
-template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0, bool BASIC = false>
-__global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
+//   LEAN     bit 0: the scene's materials are the three basic ones: lean shading (material_scatter<BASIC>); bit 1: one pass of at most 32 small groups behind the
+//            cell-table prefilter (scan_pairs<ONEPASS>); only with SCENE = 0 and without DBG.  Both together need 103 VGPRs instead of 128; bit 2 (with both):
+//            compiled for SIX waves per SIMD (80 VGPRs, ~20 of them spilled) and launched as two 12-wave workgroups per CU - see launch_spheres for when
+template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0, int LEAN = 0>
+__global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* unused;
     const SceneLds S = stage_scene<false, SCENE>(P, smem, &unused);
@@ -1567,7 +1583,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_render_spheres_queue(const RtSp
             }
             if (sel) { nrays++; pix_rays++; }
             if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            const bool done = trace_rays<false, DBG, BASIC>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
+            const bool done = trace_rays<false, DBG, (LEAN & 1) != 0, (LEAN & 2) != 0>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
             if (dbg_timers) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel, steps > 1);
         }
@@ -1616,11 +1632,11 @@ __global__ void __launch_bounds__(256) k_sum_chunks(const RtSphereParams P) {
 }  // namespace
 
 constexpr size_t kStaticLds = 1024;          // what the kernels declare statically beside the dynamic allocation (the queue words), rounded up
-static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg) {
+static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg, bool onepass = false) {
     // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
     const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 + (size_t)kCellCount * rt_cell_words(n_padded / kSphereGroup) * 16;
-    const size_t scratch = (size_t)waves * kWaveScratch;
+    const size_t scratch = (size_t)waves * ws_total(onepass);
     if (scene == 1) return scratch;
     if (scene == 2) return test_data + (size_t)n_padded * 4 + scratch;
     return test_data + (size_t)n_padded * 16 + (size_t)n_padded * 12 +
@@ -1653,28 +1669,27 @@ static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned b
 
 static int g_queue_threads = kThreads;      // workgroup size of the persistent kernel for the scene being launched (launch_spheres: 16 waves, or 8 when only that fits)
 
+static int g_lean = 0;                      // LEAN bits of the instantiation launch_spheres chose for the scene being launched (0 = the general kernel)
+
 template <int PHASE, int CLS, bool CHUNKED, int SCENE>
 static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned blocks, size_t lds, hipStream_t stream, uint32_t stride, int cfg, int chain_cfg, int caps) {
-    // the attribute goes on the function that is launched (the diagnostic instantiation is a different function)
-    const bool counting = q.wave_dbg != nullptr || q.counters != nullptr;          // the diagnostic instantiation also counts the reference's ray statistics
-    const void* kern = counting ? reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>)
-                                  : reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    static const bool basic_env = !(getenv("RT_BASIC") && getenv("RT_BASIC")[0] == '0');       // A/B: RT_BASIC=0 keeps the general shading code
-    if (counting) hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
-    else if (SCENE == 0 && q.basic_materials && basic_env) {
-        const void* kb = reinterpret_cast<const void*>(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, true>);
+    // (the diagnostic instantiation - counters, the reference's ray statistics, time stamps - is the general kernel: launch_spheres leaves g_lean at 0 for it)
+    const bool counting = q.wave_dbg != nullptr || q.counters != nullptr;
+    auto go = [&](auto kern) -> hipError_t {
+        // the attribute goes on the function that is launched
         if (lds > 64 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, true>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
-    }
-    else hipLaunchKernelGGL((k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>), dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
-    return hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
+        return hipGetLastError();
+    };
+    if (counting) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>);
+    if (SCENE == 0 && g_lean == 7) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 7>);
+    if (SCENE == 0 && g_lean == 3) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 3>);
+    if (SCENE == 0 && g_lean == 1) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 1>);
+    if (SCENE == 0 && g_lean == 2) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 2>);
+    return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
 }
 
 // `hybrid`: stage_scene's form 2 (test data in the LDS, hit data in global memory)
@@ -1719,9 +1734,30 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         else if (lds_bytes(p.n_padded, p.n, false, 2, 16) <= kLdsPerCu) { hybrid = true; waves = 16; }
         else { hybrid = true; waves = 8; }
     }
-    g_queue_threads = 64 * waves;
-    const size_t lds = kind == 1 ? lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) : lds_bytes(p.n_padded, p.n, false, hybrid ? 2 : 0, waves);
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
+    // Lean instantiations of the persistent kernel (template parameter LEAN), chosen by what the scene is: bit 0 = its materials are the three basic ones,
+    // bit 1 = its small groups take one pass behind the cell-table prefilter.  Both together need 103 VGPRs where the general kernel fills its 128 (C5 at
+    // 256 spp: 10530 -> 11515 Msamples/s, C2 7800 -> 8580; profiles/r04_ab_lean_c5.txt), and compiled for 80 (LEAN = 7) they run SIX waves per SIMD as two
+    // 12-wave workgroups per CU with a scene copy each (the one-pass scratch is 1.3 KB per wave smaller: ws_total; workgroups must be a multiple of four
+    // waves to pack - a workgroup's waves go round the SIMDs from SIMD 0, two 10-wave workgroups do not fit five per SIMD: tools/mb_occupancy.hip).
+    // Six waves buy throughput with latency: +11 % on a 3840x2160 frame, -10 % on a 1200x800 one at 100 AND at 1000 spp - a frame is as long as its
+    // throughput or its slowest pixels allow, whichever is longer, and the slowest pixels (6-12 rays per sample in dense waves, one ray per iteration) get
+    // slower with every wave that shares the SIMD; both scale with spp, so the pixel count decides: 1920x1080 -4 %, 2560x1440 +9 %, 3200x1800 +10 %
+    // (profiles/r04_ab_lean6_sizes.txt).  RT_BASIC=0 / RT_ONEPASS=0 / RT_LEAN6_PIXELS=<n> (0 = never): A/B.
+    static const bool basic_env = !(getenv("RT_BASIC") && getenv("RT_BASIC")[0] == '0');
+    static const bool onepass_env = !(getenv("RT_ONEPASS") && getenv("RT_ONEPASS")[0] == '0');
+    static const long long lean6_pixels = getenv("RT_LEAN6_PIXELS") ? atoll(getenv("RT_LEAN6_PIXELS")) : 2600000ll;
+    const bool counting = p.wave_dbg != nullptr || p.counters != nullptr;
+    g_lean = 0;
+    int lean_wgs = 1;
+    if (kind == 0 && !p.global_scene && !hybrid && !counting) {
+        if (p.basic_materials && basic_env) g_lean |= 1;
+        if (cull && p.cell_on != 0 && p.n_groups > p.n_big_groups && p.n_groups - p.n_big_groups <= 32 && onepass_env) g_lean |= 2;
+        if (g_lean == 3 && lean6_pixels > 0 && (long long)p.nx * p.part.local_rows >= lean6_pixels &&
+            2 * (lds_bytes(p.n_padded, p.n, false, 0, 12, true) + kStaticLds) <= (size_t)160 * 1024) { g_lean = 7; waves = 12; lean_wgs = 2; }
+    }
+    g_queue_threads = 64 * waves;
+    const size_t lds = kind == 1 ? lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) : lds_bytes(p.n_padded, p.n, false, hybrid ? 2 : 0, waves, (g_lean & 2) != 0);
     // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)
     const int pb = (variant >> 27) & 7;
     // bits 30..31: a wave switches to the sparse form at <= 4 / 8 / 12 / 16 live rays (0 = default)
@@ -1750,7 +1786,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = 1;      // one workgroup = the residency the kernel's launch bound (4 waves/SIMD, 128 VGPRs) and the LDS allow
+    if (wg_per_cu == 0) wg_per_cu = lean_wgs;   // one workgroup = the residency the kernel's launch bound (4 waves/SIMD, 128 VGPRs) and the LDS allow; the lean kernel: two of 10 waves
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + g_queue_threads - 1) / g_queue_threads;      // never more lanes than pixels
@@ -1776,7 +1812,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // among them every pixel above 3000 rays) holds nothing else and traces it in the single-ray form, the others hold up to kSparseRays.  Round 3, after
     // the dense iteration had gained 4 %: 7300 against 7117 Msamples/s with 512 waves x 4 pixels (profiles/r03_sweep_tail5.txt, r03_sweep_tail6.txt; a flat
     // basin: 768 waves, list 0 from 20..26 rays per sample, 2..4 pixels for the other lists all within 0.5 %; 1024 waves -2 %, list 0 from 30: -6 %).
-    int chain_cfg = 1 | ((waves == 16 ? 3 : 1) << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
+    int chain_cfg = 1 | ((waves == 16 ? 3 : (waves >= 10 ? 2 : 1)) << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
     int caps = 1 | (4 << 4) | (4 << 8) | (4 << 12);     // pixels a chain wave holds while one of them comes from chain list 0 / 1 / 2 / 3
     int cfg = cull | (boost << 8) | (sparse_max << 16);
     static const bool chain_single = !(getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '0');  // chain waves grab one pixel at a time
