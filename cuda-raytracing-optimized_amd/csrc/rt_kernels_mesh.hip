@@ -20,6 +20,7 @@
 #include "rt_params.h"
 
 #include <float.h>
+#include <cstdlib>
 
 using namespace rtd;
 
@@ -276,29 +277,29 @@ constexpr int kMinTraversing = 40;
 constexpr uint32_t kLeafCntLds = 32768;     // leaves whose triangle counts the default kernel keeps in the LDS (one byte each, beside its 5 KB of pair-round scratch)
 
 struct Job {
-    Ray r;
+    f3 d, inv;              // unit direction and its reciprocal (ray.h:9, intersections.h:28); the ORIGIN is the path's `org`: every job of a path starts there,
+                            // and `org` only moves in PROCESS, when no job is running
     int idx;                // 0 = traversal finished
     uint32_t bitStack;
     float closest;          // running closest t (t_max at start)
-    float t_min;
     uint32_t triId;
-    float hu, hv;
+    float hu, hv;           // (only a textured material reads them: the lean instantiation does not carry them)
     bool shadow;
     uint32_t ax, ay, az;    // byte offsets of the ray's (near_L, near_R, far_L, far_R) on each axis inside a bvh_axis record
 };
 
-__device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org, f3 dir, float t_min, float t_max, bool shadow) {
-    J.r = make_ray(org, dir);
+__device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org, f3 dir, float t_max, bool shadow) {
+    const Ray r = make_ray(org, dir);
+    J.d = r.d; J.inv = r.inv;
     J.shadow = shadow;
-    J.t_min = t_min;
     J.closest = t_max;
     J.bitStack = 1;
     J.triId = 0; J.hu = 0.0f; J.hv = 0.0f;
-    J.ax = J.r.inv.x < 0.0f ? 16u : 0u;                  // `if (invD < 0.0f) swap(t0, t1)`, intersections.h:30, as a choice of address
-    J.ay = J.r.inv.y < 0.0f ? 48u : 32u;
-    J.az = J.r.inv.z < 0.0f ? 80u : 64u;
+    J.ax = r.inv.x < 0.0f ? 16u : 0u;                    // `if (invD < 0.0f) swap(t0, t1)`, intersections.h:30, as a choice of address
+    J.ay = r.inv.y < 0.0f ? 48u : 32u;
+    J.az = r.inv.z < 0.0f ? 80u : 64u;
     // hitMesh, kernels.cu:296-323: scene bounds first; a miss reports FLT_MAX
-    if (hit_bbox(ld3(P.bounds.min), ld3(P.bounds.max), J.r, t_max)) {
+    if (hit_bbox(ld3(P.bounds.min), ld3(P.bounds.max), r, t_max)) {
         J.idx = 1;
     } else {
         J.idx = 0;
@@ -312,8 +313,14 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
 // after a diffuse hit; Russian roulette and the light sample draw in the reference's order, the shadow result is added before
 // anything else: bit-exact.  One PROCESS per bounce instead of two (-31 % process steps), 33 instead of 31 lanes per node step -
 // but every node step had to select the lane's job (+28 % cycles per step): 573-590 against 609 Msamples/s.  Not kept.)
-template <int TRAV, bool DBG, bool STATS>
-__global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
+// LEAN (the launcher's promise: every material is RT_DIFFUSE / RT_METAL / RT_GLASS without a texture - what scene_materials.h:13-20 at HEAD can produce -, no
+// floor plane, pair rounds available): PROCESS without the preset tables, textures and the plane, no (u, v) carried through the traversal - fewer registers,
+// so more waves per SIMD (RT_MESH_LEAN_WAVES) to hide the dependent node loads behind.
+#ifndef RT_MESH_LEAN_WAVES
+#define RT_MESH_LEAN_WAVES 4
+#endif
+template <int TRAV, bool DBG, bool STATS, bool LEAN = false>
+__global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV == 0 ? 4 : 5)) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
@@ -354,8 +361,8 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
     bool inside = false, specular = false;
     uint32_t pixelId = 0;
     Job J;
-    J.idx = 0; J.shadow = false; J.closest = FLT_MAX; J.bitStack = 1; J.t_min = eps; J.triId = 0; J.hu = J.hv = 0.0f;
-    J.r.o = F3(0, 0, 0); J.r.d = F3(0, 0, 1); J.r.inv = F3(0, 0, 1);
+    J.idx = 0; J.shadow = false; J.closest = FLT_MAX; J.bitStack = 1; J.triId = 0; J.hu = J.hv = 0.0f;
+    J.d = F3(0, 0, 1); J.inv = F3(0, 0, 1);
     bool have_pixel = false, exhausted = false;
     TravStats st = { 0, 0 };
     uint32_t nrays = 0, nshadow = 0;
@@ -429,7 +436,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     normal = unit(cross(e1, e2));
                     const rt_material mat = P.materials[mesh_id];    // kernels.cu:452-480
                     mtype = mat.type; mparam = mat.param;
-                    if (mat.texId != -1) {
+                    if (!LEAN && mat.texId != -1) {
                         const float* tc = P.tris[J.triId].texCoords;
                         const float w0 = 1 - J.hu - J.hv;
                         const float tcu = (J.hu * tc[2] + J.hv * tc[4] + w0 * tc[0]);
@@ -448,10 +455,11 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     }
                 } else {
                     float tp = FLT_MAX;
-                    if (P.floor_on) tp = plane_hit(ld3(P.floor.norm), ld3(P.floor.point), J.r, eps, FLT_MAX);   // kernels.cu:341-345, re-enabled by rt_render_options.floor
+                    Ray jr; jr.o = org; jr.d = J.d; jr.inv = J.inv;
+                    if (!LEAN && P.floor_on) tp = plane_hit(ld3(P.floor.norm), ld3(P.floor.point), jr, eps, FLT_MAX);   // kernels.cu:341-345, re-enabled by rt_render_options.floor
                     if (tp < FLT_MAX) {
                         obj = 2; t_hit = tp; normal = ld3(P.floor.norm);
-                    } else if (specular && sphere_hit(lightC, lightR, J.r, eps, FLT_MAX) < FLT_MAX) {           // kernels.cu:346
+                    } else if (specular && sphere_hit(lightC, lightR, jr, eps, FLT_MAX) < FLT_MAX) {             // kernels.cu:346
                         obj = 3;
                     }
                 }
@@ -466,9 +474,9 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         if (!P.nee) pcolor = pcolor + atten * ld3(P.lightColor);                                // kernels.cu:440-446
                         path_done = true;
                     } else {
-                        if (dot(J.r.d, normal) > 0.0f) normal = -normal;                                        // kernels.cu:354-355
+                        if (dot(J.d, normal) > 0.0f) normal = -normal;                                          // kernels.cu:354-355
                         Scatter sc;
-                        material_scatter(sc, t_hit, J.r.o + t_hit * J.r.d, normal, inside, dir, mtype, albedo, mparam, rng);
+                        material_scatter<LEAN>(sc, t_hit, org + t_hit * J.d, normal, inside, dir, mtype, albedo, mparam, rng);
                         org = org + sc.t * dir;                      // kernels.cu:485-489
                         dir = sc.wi;
                         atten = atten * sc.throughput;
@@ -568,7 +576,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
         if (need_sample) { start_sample(); need_sample = false; }    // one site for "path ended" and "new pixel"
         if (want_job) {
             const bool sh = want_job == 2;
-            job_start(P, J, org, sh ? shadow_dir : dir, eps, sh ? pend_dist : FLT_MAX, sh);
+            job_start(P, J, org, sh ? shadow_dir : dir, sh ? pend_dist : FLT_MAX, sh);
             if (STATS && J.idx == 0) stat(sh ? RT_STAT_SHADOWS_BBOX_NOHITS : (bounce == 0 ? RT_STAT_PRIMARY_BBOX_NOHITS : RT_STAT_SECONDARY_BBOX_NOHIT));   // kernels.cu:298-301
             want_job = 0;
         }
@@ -617,12 +625,12 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         // `x < closest` = hit && entry < closest (closest <= FLT_MAX), `rightHit < leftHit` = as below when one side is taken.
                         // hit_bbox_dist (intersections.h:25-41) per box: t_min from 0.001f, t_max from closest, v_max / v_min updates (rt_device.h slab)
                         float le = 0.001f, re = 0.001f, lx = J.closest, rx = J.closest;
-                        le = fmaxf((px.x - J.r.o.x) * J.r.inv.x, le); lx = fminf((px.z - J.r.o.x) * J.r.inv.x, lx);
-                        re = fmaxf((px.y - J.r.o.x) * J.r.inv.x, re); rx = fminf((px.w - J.r.o.x) * J.r.inv.x, rx);
-                        le = fmaxf((py.x - J.r.o.y) * J.r.inv.y, le); lx = fminf((py.z - J.r.o.y) * J.r.inv.y, lx);
-                        re = fmaxf((py.y - J.r.o.y) * J.r.inv.y, re); rx = fminf((py.w - J.r.o.y) * J.r.inv.y, rx);
-                        le = fmaxf((pz.x - J.r.o.z) * J.r.inv.z, le); lx = fminf((pz.z - J.r.o.z) * J.r.inv.z, lx);
-                        re = fmaxf((pz.y - J.r.o.z) * J.r.inv.z, re); rx = fminf((pz.w - J.r.o.z) * J.r.inv.z, rx);
+                        le = fmaxf((px.x - org.x) * J.inv.x, le); lx = fminf((px.z - org.x) * J.inv.x, lx);
+                        re = fmaxf((px.y - org.x) * J.inv.x, re); rx = fminf((px.w - org.x) * J.inv.x, rx);
+                        le = fmaxf((py.x - org.y) * J.inv.y, le); lx = fminf((py.z - org.y) * J.inv.y, lx);
+                        re = fmaxf((py.y - org.y) * J.inv.y, re); rx = fminf((py.w - org.y) * J.inv.y, rx);
+                        le = fmaxf((pz.x - org.z) * J.inv.z, le); lx = fminf((pz.z - org.z) * J.inv.z, lx);
+                        re = fmaxf((pz.y - org.z) * J.inv.z, re); rx = fminf((pz.w - org.z) * J.inv.z, rx);
                         const bool hl = !(lx < le), hr = !(rx < re);
                         const bool traverseLeft = hl && le < J.closest;
                         const bool traverseRight = hr && re < J.closest;
@@ -668,12 +676,12 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                             const bool pv = pair_ok && r < n_serve;
                             const uint32_t owner = pv ? w_owner[r] : lane;
                             const int src = (int)(owner << 2);
-                            const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.x)));
-                            const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.y)));
-                            const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.o.z)));
-                            const float dx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.d.x)));
-                            const float dy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.d.y)));
-                            const float dz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.r.d.z)));
+                            const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(org.x)));
+                            const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(org.y)));
+                            const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(org.z)));
+                            const float dx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.d.x)));
+                            const float dy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.d.y)));
+                            const float dz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.d.z)));
                             const float o_closest = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(J.closest)));
                             const uint32_t o_packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)packed);
                             const bool o_shadow = (o_packed & 0x80000000u) != 0u;
@@ -704,7 +712,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                                 const unsigned long long best = w_best[owner];
                                 // tests the reference executes: every reached triangle; a shadow ray stops after its first hit
                                 if (COUNT && reached && (!o_shadow || best == ~0ull || (unsigned long long)pair_k <= best)) st.tests++;
-                                if (hit && key == best) w_uv[owner] = make_float2(u, v);
+                                if (!LEAN && hit && key == best) w_uv[owner] = make_float2(u, v);
                             }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -714,8 +722,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         const bool served = at_leaf && (int)my_rank < n_serve;
                         if (served) {
                             my_best = w_best[lane];
-                            const float2 uv = w_uv[lane];
-                            my_u = uv.x; my_v = uv.y;
+                            if (!LEAN) { const float2 uv = w_uv[lane]; my_u = uv.x; my_v = uv.y; }
                         }
                         if (served) {
                             if (my_best != ~0ull && J.shadow) {          // any-hit: hitBvh returns 0.0f (kernels.cu:205)
@@ -725,7 +732,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                                 if (my_best != ~0ull) {
                                     J.closest = __uint_as_float((uint32_t)(my_best >> 32));
                                     J.triId = ((uint32_t)J.idx - P.first_leaf) * P.nppl + (uint32_t)(my_best & 0xFFFFFFFFull);
-                                    J.hu = my_u; J.hv = my_v;
+                                    if (!LEAN) { J.hu = my_u; J.hv = my_v; }
                                 }
                                 const int m = __ffs((int)J.bitStack) - 1;
                                 J.bitStack = (J.bitStack >> m) ^ 1u;
@@ -743,7 +750,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                             const float cx = pt[2].x;
                             float u, v;
                             if (COUNT) st.tests++;
-                            const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
+                            const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), Ray{ org, J.d, J.inv }, eps, J.closest, u, v);
                             if (hitT < J.closest) {
                                 if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
                                 J.closest = hitT;
@@ -776,9 +783,9 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                     const float4* n = P.bvh4 + (size_t)J.idx * 3;
                     const float4 na = n[0], nb = n[1], nc = n[2];
                     st.nodes++;
-                    const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), J.r, J.closest);
+                    const float leftHit = hit_bbox_dist(F3(na.x, na.y, na.z), F3(na.w, nb.x, nb.y), Ray{ org, J.d, J.inv }, J.closest);
                     const bool traverseLeft = leftHit < J.closest;
-                    const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), J.r, J.closest);
+                    const float rightHit = hit_bbox_dist(F3(nb.z, nb.w, nc.x), F3(nc.y, nc.z, nc.w), Ray{ org, J.d, J.inv }, J.closest);
                     const bool traverseRight = rightHit < J.closest;
                     const bool swap = rightHit < leftHit;
                     if (traverseLeft && traverseRight) {
@@ -808,7 +815,7 @@ __global__ void __launch_bounds__(kThreads, TRAV == 0 ? 4 : 5) k_render_mesh_que
                         const float cx = pt[2].x;
                         float u, v;
                         st.tests++;
-                        const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), J.r, J.t_min, J.closest, u, v);
+                        const float hitT = triangle_hit(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), F3(b.z, b.w, cx), Ray{ org, J.d, J.inv }, eps, J.closest, u, v);
                         if (hitT < J.closest) {
                             if (J.shadow) { occluded = true; break; }    // any-hit: hitBvh returns 0.0f (kernels.cu:205)
                             J.closest = hitT;
@@ -862,7 +869,11 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int wg_per_cu = (variant >> 8) & 0xFF;
-    if (wg_per_cu == 0) wg_per_cu = (((variant >> 24) & 3) == 1) ? 5 : 4;   // = the launch bounds (96 / 128 VGPRs); the pair rounds spill at 96      // launch bound: 5 waves per SIMD (96 VGPRs); 6 gave the same rate, 8 spills
+    const bool classic0 = ((variant >> 24) & 3) == 1;
+    static const bool lean_env = !(getenv("RT_MESH_LEAN") && getenv("RT_MESH_LEAN")[0] == '0');          // A/B: RT_MESH_LEAN=0 keeps the general kernel
+    const bool lean = lean_env && !classic0 && !p.dbg && !p.counters && p.lean_ok && !p.floor_on && p.leaf_sentinels_trailing && p.leaf_ofs && p.leaf_tri &&
+                      p.nppl >= 1u && p.nppl <= 16u && p.first_leaf <= kLeafCntLds;
+    if (wg_per_cu == 0) wg_per_cu = lean ? RT_MESH_LEAN_WAVES : (classic0 ? 5 : 4);   // = the launch bounds (96 / 128 VGPRs); the pair rounds spill at 96      // launch bound: 5 waves per SIMD (96 VGPRs); 6 gave the same rate, 8 spills
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
     long long blocks = (long long)cus * wg_per_cu;
     const long long useful = (total_px + kThreads - 1) / kThreads;
@@ -890,7 +901,8 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
         else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<1, false, true>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
         else hipLaunchKernelGGL((k_render_mesh_queue<1, false, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
     } else {
-        if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
+        if (lean) hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, true>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
+        else if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<0, true, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
         else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<0, false, true>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
         else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
     }

@@ -193,7 +193,8 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
 struct Lane {
     uint32_t rng;
     f3 col;                 // pixel accumulator (kernels.cu:547)
-    f3 org, dir, atten, pcolor;
+    f3 org, dir, atten;     // (the path's colour, path::color of helper_structs.h:57, is not carried: a sphere-scene path collects light once, when it ends in the
+                            //  sky - shade() hands that sample colour to the caller, 0 + attenuation * sky as kernels.cu:397,419-421 compute it)
     int bounce;
     bool inside;
     int s;                  // sample index within the pixel
@@ -214,7 +215,6 @@ __device__ __forceinline__ void start_sample(const PP& P, Lane& L) {
     get_ray(P.cam, u, v, L.rng, L.org, d);
     L.dir = unit(d);                                                 // ray.h:9 (get_ray returns a ray)
     L.atten = F3(1.0f, 1.0f, 1.0f);
-    L.pcolor = F3(0, 0, 0);
     L.bounce = 0;
     L.inside = false;
 }
@@ -930,7 +930,7 @@ __device__ __forceinline__ Hit scan_single(const RtSphereParams& P, const SceneL
 }
 
 // ---- shading of one hit / miss: the rest of color()'s loop body (kernels.cu:415-531) -------------------------------
-// Returns true when the path ended (the caller accumulates L.pcolor and starts the next sample).
+// Returns true when the path ended; `sample` is then the path's colour (the caller adds it to the pixel's sum and starts the next sample).
 // The reference's `#ifdef STATS` ray statistics (kernels.cu:47-67,399-432,514-531) for sphere scenes, counted when P.counters is set (an untimed run): a
 // sphere scene's spheres are its "mesh" (the oracle counts them the same way), so SECONDARY_MESH = SECONDARY and SECONDARY_NOHIT = 0; there are no
 // scene-bounds, shadow or BVH statistics.  One device atomic per wave and event (hipcc folds the per-lane adds of a wave into one).  Compiled into the
@@ -940,7 +940,8 @@ template <bool STATS>
 __device__ __forceinline__ void ray_stat(const RtSphereParams& P, int k) { if (STATS && P.counters) atomicAdd(&P.counters->ref_stats[k], 1ull); }
 
 template <bool STATS, bool BASIC = false>
-__device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S, Lane& L, f3 dn, Hit h) {
+__device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S, Lane& L, f3 dn, Hit h, f3& sample) {
+    sample = F3(0, 0, 0);                                            // kernels.cu:397
     const bool primary = L.bounce == 0;
     if (STATS && P.counters) {                                       // kernels.cu:403-408
         ray_stat<STATS>(P, primary ? RT_STAT_PRIMARY : RT_STAT_SECONDARY);
@@ -949,7 +950,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
     }
     if (h.sid < 0) {
         ray_stat<STATS>(P, primary ? RT_STAT_PRIMARY_NOHITS : RT_STAT_SECONDARY_MESH_NOHIT);      // kernels.cu:414-417
-        L.pcolor = L.pcolor + L.atten * sky_color(P.sky, L.dir);     // kernels.cu:419-425
+        sample = sample + L.atten * sky_color(P.sky, L.dir);         // kernels.cu:419-425 (0 + x: kept as an addition, -0 would become +0)
         return true;
     }
     if (primary) ray_stat<STATS>(P, RT_STAT_PRIMARY_HIT_MESH);              // kernels.cu:428-432
@@ -987,7 +988,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
 template <bool LEGACY, bool STATS = false, bool BASIC = false, bool ONEPASS = false>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
-                                           uint32_t& groups_done, uint32_t& boxes_done, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
+                                           uint32_t& groups_done, uint32_t& boxes_done, f3& sample, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
@@ -1021,7 +1022,7 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
         }
     }
     bool done = false;
-    if (has_ray) done = shade<STATS, BASIC>(P, S, L, dn, h);
+    if (has_ray) done = shade<STATS, BASIC>(P, S, L, dn, h, sample);
     lap(5);
     return done;
 }
@@ -1050,9 +1051,10 @@ __global__ void __launch_bounds__(kThreads) k_render_spheres_tiles(const RtSpher
 
     while (__ballot(active) != 0ull) {                               // wave-uniform loop: idle lanes stay to help
         if (active) nrays++;
-        const bool done = trace_rays<LEGACY>(P, S, L, active, coop_below, cull != 0, groups_done, boxes_done);
+        f3 sample;
+        const bool done = trace_rays<LEGACY>(P, S, L, active, coop_below, cull != 0, groups_done, boxes_done, sample);
         if (active && done) {
-            L.col = L.col + L.pcolor;                                // kernels.cu:558
+            L.col = L.col + sample;                                  // kernels.cu:558
             L.s++;
             if (L.s < P.ns) start_sample(P, L);
             else active = false;
@@ -1385,10 +1387,10 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
     // times per iteration; the lanes are flagged instead and ONE site after the refill starts them all.  Only a boosted
     // wave starts the sample at once (`now`), because its heavy lanes trace again within the same iteration.
     bool need_sample = false;
-    auto finish = [&](bool fin, bool now) {
+    auto finish = [&](bool fin, bool now, f3 sample) {
         if (fin) {
-            if (DBG && P.counters && (isnan(L.pcolor.x) || isnan(L.pcolor.y) || isnan(L.pcolor.z))) ray_stat<DBG>(P, RT_STAT_NAN);      // kernels.cu:559-561
-            L.col = L.col + L.pcolor;                                // kernels.cu:558
+            if (DBG && P.counters && (isnan(sample.x) || isnan(sample.y) || isnan(sample.z))) ray_stat<DBG>(P, RT_STAT_NAN);      // kernels.cu:559-561
+            L.col = L.col + sample;                                  // kernels.cu:558
             L.s++;
             if (L.s < s_end_of()) {
                 if (now) start_sample<PHASE == 0>(sample_params(), L); else need_sample = true;
@@ -1583,9 +1585,10 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
             }
             if (sel) { nrays++; pix_rays++; }
             if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-            const bool done = trace_rays<false, DBG, (LEAN & 1) != 0, (LEAN & 2) != 0>(P, S, L, sel, -1, cull, groups_done, boxes_done, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
+            f3 sample;
+            const bool done = trace_rays<false, DBG, (LEAN & 1) != 0, (LEAN & 2) != 0>(P, S, L, sel, -1, cull, groups_done, boxes_done, sample, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
             if (dbg_timers) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
-            finish(done && sel, steps > 1);
+            finish(done && sel, steps > 1, sample);
         }
     }
 

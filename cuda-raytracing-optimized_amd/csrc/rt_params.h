@@ -113,6 +113,7 @@ struct RtMeshParams {
     uint32_t first_leaf;
     uint32_t nppl;
     int32_t leaf_sentinels_trailing;   // host-checked: no real triangle behind a sentinel in any leaf (pair rounds allowed)
+    int32_t lean_ok;            // host-checked: every material is RT_DIFFUSE / RT_METAL / RT_GLASS and untextured (the lean instantiation may run)
     rt_bbox bounds;
     const rt_material* materials;
     const float* const* tex_data;

@@ -741,6 +741,9 @@ void runRenderer(int ns, int tx, int ty) {
             p.leaf_tri = compact_leaves ? d.d_leaf_tri : nullptr; p.leaf_ofs = compact_leaves ? d.d_leaf_ofs : nullptr;
             p.first_leaf = (uint32_t)c.num_bvh_nodes / 2; p.nppl = (uint32_t)c.nppl; p.bounds = c.bounds;
             p.leaf_sentinels_trailing = c.leaf_sentinels_trailing;
+            p.lean_ok = 1;
+            for (const rt_material& m : c.h_materials)
+                if ((m.type != RT_DIFFUSE && m.type != RT_METAL && m.type != RT_GLASS) || m.texId != -1) p.lean_ok = 0;
             p.materials = d.d_materials;
             p.tex_data = d.d_tex_data; p.tex_width = d.d_tex_width; p.tex_height = d.d_tex_height;
             p.fb = d.d_fb; p.part = part;
