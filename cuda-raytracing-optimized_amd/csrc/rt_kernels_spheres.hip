@@ -59,7 +59,7 @@ namespace {
 
 #ifndef RT_BOX_CUT
 #define RT_BOX_CUT 12       // group_needs_cells: the per-lane box loop stops when fewer lanes than this still have candidates (A/B on C5 at 256 spp, profiles/r04_ab_basic_c5.txt:
-                            // off 10870, 8: 10930, 12: 10945, 20: 10945 Msamples/s)
+                            // 1 (never): 10870, 8: 10930, 12: 10945, 20: 10945 Msamples/s)
 #endif
 constexpr int kWavesPerWg = 16;             // 16 waves - a whole CU at 4 waves per SIMD - share ONE LDS copy of the scene (tile kernel: 16 tiles side by side)
 constexpr int kThreads = 64 * kWavesPerWg;
@@ -74,7 +74,6 @@ __host__ __device__ constexpr int ws_cand_cap(bool onepass) { return onepass ? 1
 __host__ __device__ constexpr int ws_list_cap(bool onepass) { return onepass ? 64 * 8 + 64 : 64 * kPassGroups + 64; }
 __host__ __device__ constexpr int ws_pairs(bool onepass) { return 64 * 32 + 64 * 8 + ws_list_cap(onepass) * 2; }
 __host__ __device__ constexpr int ws_total(bool onepass) { return ws_pairs(onepass) + ws_cand_cap(onepass) * 4 + 16; }
-constexpr int kListCap = ws_list_cap(false);
 constexpr int kWaveScratch = ws_total(false);
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
@@ -159,16 +158,16 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
     float4* s_sph = reinterpret_cast<float4*>(smem);
     float4* s_grp = s_sph + P.n_padded + P.n_groups;
     if (SCENE == 2) {
-        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups));
+        int* s_org = reinterpret_cast<int*>(s_grp + 3 * P.n_groups + rt_cell_f4(P.n_groups));
         for (int k = threadIdx.x; k < P.n_padded + P.n_groups; k += (int)blockDim.x) s_sph[k] = P.spheres[k];
         for (int k = threadIdx.x; k < P.n_padded; k += (int)blockDim.x) s_org[k] = P.orig[k];
-        for (int k = threadIdx.x; k < 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups); k += (int)blockDim.x) s_grp[k] = P.groups[k];     // (boxes + their cell tables)
+        for (int k = threadIdx.x; k < 3 * P.n_groups + rt_cell_f4(P.n_groups); k += (int)blockDim.x) s_grp[k] = P.groups[k];     // (boxes + their cell tables)
         *after = nullptr;
         unsigned char* scratch = reinterpret_cast<unsigned char*>(s_org + P.n_padded);
         __syncthreads();
         return { s_sph, s_grp, P.mat_color, P.mat_type, s_org, P.slot_of, P.rad, scratch };
     }
-    float4* s_mat = s_grp + 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups);
+    float4* s_mat = s_grp + 3 * P.n_groups + rt_cell_f4(P.n_groups);
     int*    s_typ = reinterpret_cast<int*>(s_mat + P.n_padded);
     int*    s_org = s_typ + P.n_padded;
     float*  s_rad = reinterpret_cast<float*>(s_org + P.n_padded);
@@ -180,7 +179,7 @@ __device__ __forceinline__ SceneLds stage_scene(const RtSphereParams& P, unsigne
         s_typ[k] = P.mat_type[k];
         s_org[k] = P.orig[k];
     }
-    for (int k = threadIdx.x; k < 3 * P.n_groups + kCellCount * rt_cell_words(P.n_groups); k += (int)blockDim.x) s_grp[k] = P.groups[k];
+    for (int k = threadIdx.x; k < 3 * P.n_groups + rt_cell_f4(P.n_groups); k += (int)blockDim.x) s_grp[k] = P.groups[k];
     for (int k = threadIdx.x; k < P.n; k += (int)blockDim.x) s_sof[k] = P.slot_of[k];
     float* s_fb = reinterpret_cast<float*>(s_sof + ((P.n + 3) & ~3));
     *after = s_fb;                                                   // WITH_FB (tile kernel): kThreads x 3 floats of framebuffer staging
@@ -402,7 +401,9 @@ __device__ __forceinline__ uint32_t group_needs_shared(const SceneLds& S, int g0
     return __brev(~skip << (32 - ng));
 }
 
-// The same test behind a PREFILTER (scenes of <= 32 small groups that share the y axis, RtSphereParams::cell_on): the part of the ray inside the shared
+// The prefilter for scenes whose group boxes SHARE an axis (template AX; spheres resting on a plane: the benchmark) - group_needs_cells below with the shared
+// slab in place of the union box and a two-axis box test (8 instead of 12 instructions per box; the union clip and the third table cost the benchmark frame
+// 5 %, profiles/r04_ab_cells3_c5.txt): the part of the ray inside the shared
 // slab - t in [in0, out0], already clipped to [0, closest hit] - has a bounding rectangle on the two other axes, and the host's cell tables give, per cell,
 // the boxes that begin at or below it and those that end at or above it: four LDS words and three ANDs leave the boxes whose rectangle overlaps the
 // ray's (on the benchmark scene 2-3 of the 31), and only those take the box test, two per step of a per-lane loop: the wave runs as many steps as
@@ -415,8 +416,8 @@ __device__ __forceinline__ uint32_t group_needs_shared(const SceneLds& S, int g0
 // the cell index is off by less than the tables' slack.  An infinite or NaN end point (no hit yet and a ray parallel to the slab) clamps to
 // the first / last cell, whose words reject nothing.
 template <int AX>
-__device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& r, f3 org, f3 dn,
-                                                      float shared_lo, float shared_hi, uint32_t& boxes_done, int word) {
+__device__ __forceinline__ uint32_t group_needs_cells_shared(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& r, f3 org, f3 dn,
+                                                             float shared_lo, float shared_hi, uint32_t& boxes_done, int word) {
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     constexpr int A1 = (AX + 1) % 3, A2 = (AX + 2) % 3;
     const float* f = reinterpret_cast<const float*>(S.grp + 3 * g0);
@@ -434,7 +435,7 @@ __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, c
         const float c_hi = fmaxf(fminf(__builtin_fmaf(hi, P.cell_scale[q], P.cell_off[q]), (float)(kCellCount - 1)), 0.0f);
         return tab[__umul24((uint32_t)(2 * kCellCount * q) + (uint32_t)c_hi, (uint32_t)W)] & tab[__umul24((uint32_t)(2 * kCellCount * q + kCellCount) + (uint32_t)c_lo, (uint32_t)W)];     // (24-bit multiply: full rate)
     };
-    uint32_t cand = overlap(comp<A1>(org), comp<A1>(dn), 0) & overlap(comp<A2>(org), comp<A2>(dn), 1);
+    uint32_t cand = overlap(comp<A1>(org), comp<A1>(dn), A1) & overlap(comp<A2>(org), comp<A2>(dn), A2);      // (tables are indexed by axis)
     if (!(in0 <= out0)) cand = 0u;                                   // the ray misses the slab (or leaves it behind its closest hit): the box test would skip every box
     boxes_done += (uint32_t)__popc(cand);
     const float* f1 = f + 4 * A1 + bsign<A1>(r);
@@ -445,7 +446,6 @@ __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, c
         return __float_as_uint(t_out - t_in);
     };
     uint32_t need = 0;
-#if RT_BOX_CUT > 0
     // The loop below is per lane: the wave runs it as long as its lane with the most candidates needs (a grazing ray that lies long in the slab), two box
     // tests per step.  A step that serves only a few lanes costs the wave more than it can save: an untested candidate simply becomes a (ray, group) pair -
     // 16 sphere pre-tests on ONE lane of a pair round, the culling being an optimisation, never part of the result.  So the loop ends when fewer than
@@ -463,18 +463,65 @@ __device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, c
         }
     }
     return need | cand;
-#endif
-    while (cand != 0u) {                                             // (per lane: the wave runs max-over-lanes / 2 steps)
-        const int ga = __builtin_ctz(cand);
-        cand &= cand - 1u;
-        const int gb = cand != 0u ? __builtin_ctz(cand) : ga;        // (a lone last candidate is tested twice: the same bit)
-        cand &= cand - 1u;
-        const f2u a1 = *reinterpret_cast<const f2u*>(f1 + 12 * ga), a2 = *reinterpret_cast<const f2u*>(f2 + 12 * ga);
-        const f2u b1 = *reinterpret_cast<const f2u*>(f1 + 12 * gb), b2 = *reinterpret_cast<const f2u*>(f2 + 12 * gb);
-        need |= ((~gap(a1, a2)) >> 31) << ga;
-        need |= ((~gap(b1, b2)) >> 31) << gb;
+}
+
+// The box tests behind a PREFILTER (RtSphereParams::cell_on: scenes of up to 256 small groups).  The ray is first clipped to the UNION of the group boxes (one slab
+// test, the margin folded in as for every box): what is left, t in [in0, out0] inside [0, closest hit], has a bounding box, and the host's cell tables give, per
+// axis and cell, the boxes that begin at or below the cell and those that end at or above it: per axis four LDS words (two table entries for the two ends of
+// the segment's extent, `word` of each) and an AND leave the boxes whose extent overlaps the segment's on that axis; the AND over the axes whose table can reject
+// anything (cell_axes: spheres resting on a plane skip the vertical axis) leaves the boxes whose box overlaps the segment's bounding box - on the benchmark scene
+// 2-3 of the 31 - and only those take the box test, two per step of a per-lane loop: the wave runs as many steps as its lane with the most candidates needs
+// (a grazing ray that lies long in the slab), until few lanes are left (RT_BOX_CUT).  (A/B on C5 at 256 spp, round 3, profiles/r03_ab_cells.txt: uniform loop
+// 9765, prefilter 10280 Msamples/s; 64 cells per axis; 32: -0.2 %, 128: -0.3 %.)
+// Conservative by itself: a box the ray enters at t* in [0, closest] lies inside the union box, so t* is inside the union's own slab interval [in0, out0]
+// (the slab test's guarantee, with the same margin m); the entry point org + t* d (up to m, by which the segment's extent is widened here as the boxes are in
+// the test) then lies between the segment's end points on every axis - computed with two roundings each, covered by the 2^-20 relative pad - and the cell index
+// is off by less than the tables' slack.  An infinite or NaN end point (no hit yet, a ray parallel to a slab) clamps to the first / last cell, whose words
+// reject nothing.
+__device__ __forceinline__ uint32_t group_needs_cells(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& r, f3 org, f3 dn,
+                                                      uint32_t& boxes_done, int word) {
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(S.grp + 3 * P.n_groups) + word;      // this pass' 32 groups: word `word` of every set
+    const int W = rt_cell_words(P.n_groups);
+    // the union box: near / far plane per axis by the sign of the direction (BoxRay convention)
+    const float nx_ = r.sx ? P.ubox[3] : P.ubox[0], fx_ = r.sx ? P.ubox[0] : P.ubox[3];
+    const float ny_ = r.sy ? P.ubox[4] : P.ubox[1], fy_ = r.sy ? P.ubox[1] : P.ubox[4];
+    const float nz_ = r.sz ? P.ubox[5] : P.ubox[2], fz_ = r.sz ? P.ubox[2] : P.ubox[5];
+    const float t_in = fmaxf(fmaxf(__builtin_fmaf(nx_, r.inv.x, -r.cn.x), __builtin_fmaf(ny_, r.inv.y, -r.cn.y)), __builtin_fmaf(nz_, r.inv.z, -r.cn.z));
+    const float t_out = fminf(fminf(__builtin_fmaf(fx_, r.inv.x, -r.cf.x), __builtin_fmaf(fy_, r.inv.y, -r.cf.y)), __builtin_fmaf(fz_, r.inv.z, -r.cf.z));
+    const float in0 = fmaxf(t_in, 0.0f), out0 = fminf(t_out, r.cb);
+    auto overlap = [&](float o, float d, int q) -> uint32_t {
+        const float x0 = __builtin_fmaf(in0, d, o), x1 = __builtin_fmaf(out0, d, o);
+        const float pad = r.m + 9.5367431640625e-7f * (fabsf(o) + fabsf(x0) + fabsf(x1));
+        const float lo = fminf(x0, x1) - pad, hi = fmaxf(x0, x1) + pad;
+        // (a NaN goes to the permissive end: fmaxf / fminf return their other operand)
+        const float c_lo = fminf(fmaxf(__builtin_fmaf(lo, P.cell_scale[q], P.cell_off[q]), 0.0f), (float)(kCellCount - 1));
+        const float c_hi = fmaxf(fminf(__builtin_fmaf(hi, P.cell_scale[q], P.cell_off[q]), (float)(kCellCount - 1)), 0.0f);
+        return tab[__umul24((uint32_t)(2 * kCellCount * q) + (uint32_t)c_hi, (uint32_t)W)] & tab[__umul24((uint32_t)(2 * kCellCount * q + kCellCount) + (uint32_t)c_lo, (uint32_t)W)];     // (24-bit multiply: full rate)
+    };
+    uint32_t cand = ng >= 32 ? 0xFFFFFFFFu : ((1u << ng) - 1u);
+    if (P.cell_axes & 1) cand &= overlap(org.x, dn.x, 0);
+    if (P.cell_axes & 2) cand &= overlap(org.y, dn.y, 1);
+    if (P.cell_axes & 4) cand &= overlap(org.z, dn.z, 2);
+    if (!(in0 <= out0)) cand = 0u;                                   // the ray misses the union box (or leaves it behind its closest hit): the box test would skip every box
+    boxes_done += (uint32_t)__popc(cand);
+    const float4* g3 = S.grp + 3 * g0;
+    uint32_t need = 0;
+    // The loop below is per lane: the wave runs it as long as its lane with the most candidates needs, two box tests per step.  A step that serves only a few
+    // lanes costs the wave more than it can save: an untested candidate simply becomes a (ray, group) pair - 16 sphere pre-tests on ONE lane of a pair round,
+    // the culling being an optimisation, never part of the result.  So the loop ends when fewer than RT_BOX_CUT lanes still have candidates, and what they
+    // have left is taken untested.
+    while (__popcll(__ballot(cand != 0u)) >= RT_BOX_CUT) {
+        if (cand != 0u) {
+            const int ga = __builtin_ctz(cand);
+            cand &= cand - 1u;
+            const int gb = cand != 0u ? __builtin_ctz(cand) : ga;    // (a lone last candidate is tested twice: the same bit)
+            cand &= cand - 1u;
+            const float gap_a = box_gap(g3 + 3 * ga, r), gap_b = box_gap(g3 + 3 * gb, r);
+            need |= ((~__float_as_uint(gap_a)) >> 31) << ga;
+            need |= ((~__float_as_uint(gap_b)) >> 31) << gb;
+        }
     }
-    return need;
+    return need | cand;
 }
 
 __device__ __forceinline__ uint32_t group_needs(const RtSphereParams& P, const SceneLds& S, int g0, int ng, const BoxRay& br, bool cull) {
@@ -513,15 +560,18 @@ __device__ __forceinline__ int wave_inclusive_scan(int x) {
 //    reference's first-index-wins closest hit).
 // The work a wave does is proportional to the pairs that exist, not to 64 x (union of groups): incoherent waves do not
 // pay for each other's groups, and a wave with few live rays uses all 64 lanes on them.  WAVE-LEVEL: all 64 lanes call it.
-// ONEPASS (the launcher's promise: culling on, cell tables on, at most 32 small groups - the benchmark scene and everything of its size): the pass loop below
-// runs exactly once with every pass-level decision known at compile time (no windows, no carry between passes, no choice of the box test).
-template <bool ONEPASS = false>
+// One-list form (the launcher's promise: culling on, cell tables on, at most 32 x OP small groups - the benchmark scene and everything of its size): the pass
+// loop below runs exactly once with every pass-level decision known at compile time (no windows, no carry between passes, no choice of the box test).
+//   OP   words of the one-list form: 0 = the general pass loop; 1 / 2 = the scene has at most 32 / 64 small groups, which take ONE list per ray batch
+//   C3   (with OP > 0) the prefilter is the general 3-axis one (group_needs_cells) instead of the shared-vertical-axis one (group_needs_cells_shared<1>)
+template <int OP = 0, bool C3 = false>
 __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLds& S, f3 org, f3 dn, float a, bool has_ray, bool cull,
                                           uint32_t& groups_done, uint32_t& boxes_done, unsigned long long* tm = nullptr) {
     // tm (diagnostic instantiation only): cycles in [1] big spheres, [2] group boxes + pair list, [3] pair rounds, [4] candidates
     unsigned long long tc = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](int k) { if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[k] += n_ - tc; tc = n_; } };
     const int lane = threadIdx.x & 63;
+    constexpr bool ONEPASS = OP > 0;
     unsigned char* W = S.scratch + (threadIdx.x >> 6) * ws_total(ONEPASS);
     float4* w_ray = reinterpret_cast<float4*>(W);                               // ray r: (origin, a) at w_ray[r], (direction, -) at w_ray[64 + r] - two arrays of 16-byte
                                                                                 // entries: the pair lanes of a round fetch rays of (mostly) consecutive owners, and 16
@@ -616,35 +666,53 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
     int win_base = P.n_big_groups;                                   // entries hold lane << 10 | (group - win_base): a window of 1024 groups
     // A scene of up to 32 small groups (the benchmark: 31) takes ONE pass of 32: one prefix sum, one list write, one synchronisation per ray batch instead of
     // two.  A pass of 32 whose pairs would not fit the list (every ray reaching a good part of the scene: not seen) is split into quarters of 8 groups (wave-uniform).
-    const int pass_w = (ONEPASS || P.n_groups - P.n_big_groups <= 32 || (cull && P.cell_on != 0)) ? 32 : kPassGroups;
+    constexpr int NW = OP > 0 ? OP : 1;                             // need words per pass
+    const int pass_w = ONEPASS ? 32 * OP : ((P.n_groups - P.n_big_groups <= 32 || (cull && P.cell_on != 0)) ? 32 : kPassGroups);
     for (int g0 = P.n_big_groups; g0 < P.n_groups; g0 += pass_w) {
         const int ng = ONEPASS ? P.n_groups - g0 : min(pass_w, P.n_groups - g0);
         // the last pass runs the partial round too; so does a pass at the end of a 1024-group window (scenes beyond 16 k spheres only)
         const bool flush = !ONEPASS && g0 + 2 * pass_w - win_base > 1024;
         const bool last_pass = ONEPASS || g0 + pass_w >= P.n_groups || flush;
-        uint32_t need_all = 0u;
+        uint32_t need_w[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) need_w[w] = 0u;
         if (has_ray) {
-            if (ONEPASS || (cull && P.cell_on != 0)) {               // (passes of 32 groups, pass k = word k of the cell sets; shared axis y)
-                need_all = group_needs_cells<1>(P, S, g0, ng, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done, (g0 - P.n_big_groups) >> 5);
+            if (ONEPASS || (cull && P.cell_on != 0)) {               // (words of 32 groups: word k of the cell sets)
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const int gw = g0 + 32 * w, nw = min(32, P.n_groups - gw), word = (gw - P.n_big_groups) >> 5;
+                    if (w > 0 && nw <= 0) break;
+                    if (ONEPASS ? C3 : (P.box_shared_axis != 2)) need_w[w] = group_needs_cells(P, S, gw, nw, br, org, dn, boxes_done, word);
+                    else need_w[w] = group_needs_cells_shared<1>(P, S, gw, nw, br, org, dn, P.box_shared_lo, P.box_shared_hi, boxes_done, word);
+                }
             } else {
-                need_all = group_needs(P, S, g0, ng, br, cull);
+                need_w[0] = group_needs(P, S, g0, ng, br, cull);
                 boxes_done += (uint32_t)ng;
             }
         }
         // exclusive prefix sum of the pair counts over the wave
-        const int cnt_all = __popc(need_all);
+        int cnt_all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) cnt_all += __popc(need_w[w]);
         const int incl_all = wave_inclusive_scan(cnt_all);
-        // a pass of 32 whose pairs would not fit the list is cut into quarters of 8 groups (64 x 8 + the carried remainder always fit)
-        const bool split = pass_w == 32 && carry + __builtin_amdgcn_readlane(incl_all, 63) > ws_list_cap(ONEPASS);
-      for (int half = 0; half < (split ? 4 : 1); half++) {
-        const uint32_t need = split ? ((need_all >> (8 * half)) & 0xFFu) : need_all;
-        const int sg0 = g0 + (split ? 8 * half : 0);
-        const bool last_sub = last_pass && (!split || half == 3);
-        const int cnt = split ? __popc(need) : cnt_all;
+        // a pass whose pairs would not fit the list is cut into quarters of its words, 8 groups each (64 x 8 + the carried remainder always fit)
+        const bool split = pass_w >= 32 && carry + __builtin_amdgcn_readlane(incl_all, 63) > ws_list_cap(ONEPASS);
+      for (int half = 0; half < (split ? 4 * NW : 1); half++) {
+        const int sw = half >> 2, sq = half & 3;                     // (split: word and quarter of this sub-pass)
+        uint32_t need[NW];
+        int cnt = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            need[w] = split ? (w == sw ? ((need_w[w] >> (8 * sq)) & 0xFFu) << (8 * sq) : 0u) : need_w[w];
+            cnt += __popc(need[w]);
+        }
+        const bool last_sub = last_pass && (!split || half == 4 * NW - 1);
         const int incl = split ? wave_inclusive_scan(cnt) : incl_all;
         const int total = carry + __builtin_amdgcn_readlane(incl, 63);
         int at = carry + incl - cnt;
-        for (uint32_t m = need; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 10) | (sg0 - win_base + __builtin_ctz(m)));
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            for (uint32_t m = need[w]; m; m &= m - 1) w_pair[at++] = (unsigned short)((lane << 10) | (g0 + 32 * w - win_base + __builtin_ctz(m)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -717,7 +785,7 @@ __device__ __forceinline__ Hit scan_pairs(const RtSphereParams& P, const SceneLd
         // carry the remainder to the front of the list (nothing to move when no round ran - the common first pass of a 31-group scene: its ~35 pairs
         // already sit at the front - or when nothing is left)
         carry = total - stop;
-        if (!ONEPASS && stop > 0 && carry > 0) {
+        if ((!ONEPASS || split) && stop > 0 && carry > 0) {
             unsigned short moved = 0;
             if (lane < carry) moved = w_pair[stop + lane];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -986,7 +1054,7 @@ __device__ __forceinline__ bool shade(const RtSphereParams& P, const SceneLds& S
 // lanes must call it together.  With many live lanes each lane scans the sphere list for its own ray; with few
 // (the tail of a tile / of the frame, where a handful of pixels in sphere / ground wedges need thousands of rays each) the
 // whole wave works on one ray at a time, which cuts the latency of a ray ~30x and with it the critical path.
-template <bool LEGACY, bool STATS = false, bool BASIC = false, bool ONEPASS = false>
+template <bool LEGACY, bool STATS = false, bool BASIC = false, int OP = 0, bool C3 = false>
 __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneLds& S, Lane& L, bool has_ray, int coop_below, bool cull,
                                            uint32_t& groups_done, uint32_t& boxes_done, f3& sample, int sparse_max = kSparseRays, unsigned long long* tm = nullptr, bool single = false) {
     // tm (diagnostic instantiation only): cycles in [0] ray set-up, [1..4] scan_pairs, [5] shade, [6] sparse scan
@@ -1005,10 +1073,10 @@ __device__ __forceinline__ bool trace_rays(const RtSphereParams& P, const SceneL
             if (has_ray) h = hq;
             if (tm) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm[6] += n_ - tc; tc = n_; }
         } else
-        // (ONEPASS: at most 16 rays x 32 groups = 512 entries: always fits)
-        if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && (ONEPASS || (P.n_groups <= 4096 &&
-            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= kListCap))) { h = scan_sparse<ONEPASS>(P, S, L.org, dn, a, live, cull, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
-        else { h = scan_pairs<ONEPASS>(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
+        // (one list of 32 groups: at most 16 rays x 32 groups = 512 entries always fit)
+        if (__popcll(live) <= min(sparse_max, 16) && coop_below == -1 && (OP == 1 || (P.n_groups <= 4096 &&
+            (int)__popcll(live) * (P.n_groups - P.n_big_groups) <= ws_list_cap(OP > 0)))) { h = scan_sparse<(OP > 0)>(P, S, L.org, dn, a, live, cull, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
+        else { h = scan_pairs<OP, C3>(P, S, L.org, dn, a, has_ray, cull, groups_done, boxes_done, tm); if (tm) tc = __builtin_amdgcn_s_memtime(); }
     } else if (__popcll(live) >= coop_below) {
         if (has_ray) h = scan_lane_parallel(P, S, L.org, dn, a, groups_done);
     } else {
@@ -1283,9 +1351,10 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 // workgroup; 12..15 pixels a chain wave holds; 16..23 boost threshold (rays per sample); 24..27 number of chain lists; 28..31 pixels a
 // chain wave holds while one of them comes from list 0 (the longest chains).
 //   SCENE    where the scene is read from (stage_scene): 0 = an LDS copy, 1 = global memory, 2 = test data in the LDS, hit data in global memory
-//   LEAN     bit 0: the scene's materials are the three basic ones: lean shading (material_scatter<BASIC>); bit 1: one pass of at most 32 small groups behind the
-//            cell-table prefilter (scan_pairs<ONEPASS>); only with SCENE = 0 and without DBG.  Both together need 103 VGPRs instead of 128; bit 2 (with both):
-//            compiled for SIX waves per SIMD (80 VGPRs, ~20 of them spilled) and launched as two 12-wave workgroups per CU - see launch_spheres for when
+//   LEAN     bit 0: the scene's materials are the three basic ones: lean shading (material_scatter<BASIC>); bit 1: its small groups take ONE list per ray batch
+//            behind the cell-table prefilter (scan_pairs<OP>: at most 32 groups, 64 with bit 4, 128 with bit 5); bit 3: that prefilter is the general 3-axis one (no shared
+//            vertical extent: spheres scattered in space); only with SCENE = 0 and without DBG.  Bits 0 + 1 need ~100 VGPRs instead of 128; bit 2 (with
+//            both): compiled for SIX waves per SIMD (80 VGPRs, ~20 of them spilled) and launched as two 12-wave workgroups per CU - see launch_spheres for when
 template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0, int LEAN = 0>
 __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1586,7 +1655,7 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
             if (sel) { nrays++; pix_rays++; }
             if (x > 0 || steps == 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             f3 sample;
-            const bool done = trace_rays<false, DBG, (LEAN & 1) != 0, (LEAN & 2) != 0>(P, S, L, sel, -1, cull, groups_done, boxes_done, sample, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
+            const bool done = trace_rays<false, DBG, (LEAN & 1) != 0, (LEAN & 2) ? ((LEAN & 32) ? 4 : ((LEAN & 16) ? 2 : 1)) : 0, (LEAN & 8) != 0>(P, S, L, sel, -1, cull, groups_done, boxes_done, sample, sparse_max, dbg_timers ? dbg_tm : nullptr, (cfg & 4) != 0);
             if (dbg_timers) { dbg_tm[x > 0 ? 9 : 8] += 1ull; }
             finish(done && sel, steps > 1, sample);
         }
@@ -1638,7 +1707,7 @@ constexpr size_t kStaticLds = 1024;          // what the kernels declare statica
 static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int waves = kWavesPerWg, bool onepass = false) {
     // spheres + group bounds (+ material colour + type / original index / radius per slot + slot_of: scene 0; + original index: scene 2),
     // + fb staging (tile kernel only) + the per-wave scratch
-    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 + (size_t)kCellCount * rt_cell_words(n_padded / kSphereGroup) * 16;
+    const size_t test_data = (size_t)(n_padded + n_padded / kSphereGroup) * 16 + (size_t)(n_padded / kSphereGroup) * 48 + (size_t)rt_cell_f4(n_padded / kSphereGroup) * 16;
     const size_t scratch = (size_t)waves * ws_total(onepass);
     if (scene == 1) return scratch;
     if (scene == 2) return test_data + (size_t)n_padded * 4 + scratch;
@@ -1688,10 +1757,20 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
         return hipGetLastError();
     };
     if (counting) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>);
-    if (SCENE == 0 && g_lean == 7) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 7>);
-    if (SCENE == 0 && g_lean == 3) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 3>);
-    if (SCENE == 0 && g_lean == 1) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 1>);
-    if (SCENE == 0 && g_lean == 2) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, 0, 2>);
+    if (SCENE == 0 && !CHUNKED) {                                    // (the sample chunks of the counter stream take the general kernel)
+        switch (g_lean) {
+        case 1:  return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 1>);
+        case 3:  return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 3>);
+        case 7:  return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 7>);
+        case 11: return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 11>);
+        case 15: return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 15>);
+        case 19: return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 19>);
+        case 27: return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 27>);
+        case 35: return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 35>);
+        case 43: return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 43>);
+        default: break;
+        }
+    }
     return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
 }
 
@@ -1726,22 +1805,12 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     if (p.global_scene) kind = 0;               // scenes beyond the LDS: the persistent kernel only
     const size_t kLdsPerCu = 160 * 1024 - kStaticLds;
     if (lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) > kLdsPerCu) kind = 0;        // the tile kernel only knows the full copy
-    // The persistent kernel's workgroup is a whole CU's worth of waves (16: the launch bound's 4 per SIMD) around ONE scene copy - 88 KB of per-wave scratch
-    // leave 72 KB for the scene: the full copy up to ~1200 spheres (60 bytes per sphere), the hybrid one (what a sphere TEST reads in the LDS, what only a HIT
-    // reads in global memory: 21 bytes per sphere) up to ~3400; an 8-wave workgroup (44 KB of scratch, 2 waves per SIMD) keeps the hybrid copy resident up to
-    // ~5500 spheres; beyond that the same kernel reads the scene from global memory (p.global_scene, decided by the renderer with the same formula).
-    int waves = kWavesPerWg;
-    bool hybrid = false;
-    if (kind == 0 && !p.global_scene) {
-        if (lds_bytes(p.n_padded, p.n, false, 0, 16) <= kLdsPerCu) { hybrid = false; waves = 16; }
-        else if (lds_bytes(p.n_padded, p.n, false, 2, 16) <= kLdsPerCu) { hybrid = true; waves = 16; }
-        else { hybrid = true; waves = 8; }
-    }
     const int cull = ((variant >> 26) & 1) ? 0 : 1;
     // Lean instantiations of the persistent kernel (template parameter LEAN), chosen by what the scene is: bit 0 = its materials are the three basic ones,
-    // bit 1 = its small groups take one pass behind the cell-table prefilter.  Both together need 103 VGPRs where the general kernel fills its 128 (C5 at
-    // 256 spp: 10530 -> 11515 Msamples/s, C2 7800 -> 8580; profiles/r04_ab_lean_c5.txt), and compiled for 80 (LEAN = 7) they run SIX waves per SIMD as two
-    // 12-wave workgroups per CU with a scene copy each (the one-pass scratch is 1.3 KB per wave smaller: ws_total; workgroups must be a multiple of four
+    // bit 1 = its small groups (at most 128) take one list per ray batch behind the cell-table prefilter (bits 4 / 5: two / four words of 32 groups; bit 3:
+    // the general 3-axis prefilter, no shared vertical extent).  Bits 0 + 1 need ~100 VGPRs where the general kernel fills its 128 (C5 at 256 spp:
+    // 10530 -> 11515 Msamples/s, C2 7800 -> 8580; profiles/r04_ab_lean_c5.txt), and compiled for 80 (bit 2) they run SIX waves per SIMD as two
+    // 12-wave workgroups per CU with a scene copy each (the one-list scratch is 1.3 KB per wave smaller: ws_total; workgroups must be a multiple of four
     // waves to pack - a workgroup's waves go round the SIMDs from SIMD 0, two 10-wave workgroups do not fit five per SIMD: tools/mb_occupancy.hip).
     // Six waves buy throughput with latency: +11 % on a 3840x2160 frame, -10 % on a 1200x800 one at 100 AND at 1000 spp - a frame is as long as its
     // throughput or its slowest pixels allow, whichever is longer, and the slowest pixels (6-12 rays per sample in dense waves, one ray per iteration) get
@@ -1753,12 +1822,30 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     const bool counting = p.wave_dbg != nullptr || p.counters != nullptr;
     g_lean = 0;
     int lean_wgs = 1;
-    if (kind == 0 && !p.global_scene && !hybrid && !counting) {
-        if (p.basic_materials && basic_env) g_lean |= 1;
-        if (cull && p.cell_on != 0 && p.n_groups > p.n_big_groups && p.n_groups - p.n_big_groups <= 32 && onepass_env) g_lean |= 2;
-        if (g_lean == 3 && lean6_pixels > 0 && (long long)p.nx * p.part.local_rows >= lean6_pixels &&
-            2 * (lds_bytes(p.n_padded, p.n, false, 0, 12, true) + kStaticLds) <= (size_t)160 * 1024) { g_lean = 7; waves = 12; lean_wgs = 2; }
+    if (kind == 0 && !p.global_scene && !counting && p.basic_materials && basic_env && p.chunks == 1) {
+        const int n_small_groups = p.n_groups - p.n_big_groups;
+        g_lean = 1;
+        if (cull && p.cell_on != 0 && n_small_groups >= 1 && n_small_groups <= 128 && onepass_env) {
+            g_lean |= 2;                                                         // one list per ray batch
+            if (n_small_groups > 64) g_lean |= 32;                               // ... of four words
+            else if (n_small_groups > 32) g_lean |= 16;                          // ... of two
+            if (p.box_shared_axis != 2) g_lean |= 8;                             // no shared vertical extent: the 3-axis prefilter
+        }
     }
+    const bool lean_list = (g_lean & 2) != 0;                                    // (the smaller per-wave scratch)
+    // The persistent kernel's workgroup is a whole CU's worth of waves (16: the launch bound's 4 per SIMD) around ONE scene copy - 88 KB of per-wave scratch (68
+    // in the one-list kernels) leave 72 (92) KB for the scene: the full copy up to ~1200 (1500) spheres (60 bytes per sphere), the hybrid one (what a sphere TEST
+    // reads in the LDS, what only a HIT reads in global memory: 21 bytes per sphere) up to ~3400; an 8-wave workgroup (44 KB of scratch, 2 waves per SIMD) keeps
+    // the hybrid copy resident up to ~5500 spheres; beyond that the same kernel reads the scene from global memory (p.global_scene, decided by the renderer).
+    int waves = kWavesPerWg;
+    bool hybrid = false;
+    if (kind == 0 && !p.global_scene) {
+        if (lds_bytes(p.n_padded, p.n, false, 0, 16, lean_list) <= kLdsPerCu) { hybrid = false; waves = 16; }
+        else if (lds_bytes(p.n_padded, p.n, false, 2, 16) <= kLdsPerCu) { hybrid = true; waves = 16; g_lean = 0; }
+        else { hybrid = true; waves = 8; g_lean = 0; }
+    }
+    if ((g_lean & 0x32) == 2 && lean6_pixels > 0 && (long long)p.nx * p.part.local_rows >= lean6_pixels &&
+        2 * (lds_bytes(p.n_padded, p.n, false, 0, 12, true) + kStaticLds) <= (size_t)160 * 1024) { g_lean |= 4; waves = 12; lean_wgs = 2; }
     g_queue_threads = 64 * waves;
     const size_t lds = kind == 1 ? lds_bytes(p.n_padded, p.n, true, 0, kWavesPerWg) : lds_bytes(p.n_padded, p.n, false, hybrid ? 2 : 0, waves, (g_lean & 2) != 0);
     // bits 27..29: extra sparse-form rays per iteration for lanes on a long chain (0 = default 2, 7 = off)

@@ -18,9 +18,11 @@ constexpr int kSphereGroupShift = 4;
 constexpr int kSphereGroup = 1 << kSphereGroupShift;
 constexpr int kCellCount = 64;                          // cells per axis of the group boxes' cell tables (RtSphereParams::cell_on)
 constexpr int kCellWordsMax = 8;                        // the tables hold one bit per group in up to 8 words per cell: scenes of up to 256 groups (4096 spheres)
-// Words per cell for a scene of n_groups groups (0 = no tables: too many groups).  The tables - 4 x kCellCount x words words = kCellCount x words float4 - lie behind
+// Words per cell for a scene of n_groups groups (0 = no tables: too many groups).  The tables - 6 x kCellCount x words words = rt_cell_f4 float4 - lie behind
 // the 3 x n_groups box entries of RtSphereParams::groups and are staged into the LDS with them; host and kernels size them with this one function.
 __host__ __device__ inline int rt_cell_words(int n_groups) { const int w = (n_groups + 31) / 32; return w <= kCellWordsMax ? w : 0; }
+// float4 entries of the tables: 3 axes x 2 kinds (begins / ends) x kCellCount cells x words
+__host__ __device__ inline int rt_cell_f4(int n_groups) { return (6 * kCellCount * rt_cell_words(n_groups)) / 4; }
 
 struct RtPartition {
     int32_t stripe_rows;
@@ -62,12 +64,15 @@ struct RtSphereParams {
     float box_shared_lo, box_shared_hi;   // that extent
     int32_t box_shared_axis;    // 1 + axis on which every (non-empty) group box has the same extent (spheres resting on a plane), 0 = none: see group_needs
     float pair_k0;              // 2 * kPairSlack * (largest radius of the grouped spheres)^2: see the pair rounds of scan_pairs
-    // Cell tables of the group boxes (scenes whose small groups share the y axis, up to 32 x kCellWordsMax groups; see group_needs_cells): behind the 3 x n_groups box
-    // entries of `groups` lie, for each of the two other axes, kCellCount cells over the boxes' extent and per cell two sets of rt_cell_words(n_groups) words each
-    // (bit g of word g / 32 = small group g): the boxes that begin at or below the cell, the boxes that end at or above it.  Index: (((2 axis + kind) kCellCount +
-    // cell) words + word.  cell = x * cell_scale[a] + cell_off[a].
+    // Cell tables of the group boxes (scenes of up to 32 x kCellWordsMax groups; see group_needs_cells): behind the 3 x n_groups box entries of `groups` lie, for
+    // each of the three axes, kCellCount cells over the boxes' extent on that axis and per cell two sets of rt_cell_words(n_groups) words each (bit g of word
+    // g / 32 = small group g): the boxes that begin at or below the cell, the boxes that end at or above it.  Index: (((2 axis + kind) kCellCount + cell) words
+    // + word.  cell = x * cell_scale[axis] + cell_off[axis].  cell_axes: bit a = axis a's table can reject something (not every box has the same extent there:
+    // spheres resting on a horizontal plane leave bit 1 clear).  ubox: the union of the group boxes (lo.xyz, hi.xyz) the ray is clipped to first.
     int32_t cell_on;
-    float cell_scale[2], cell_off[2];
+    int32_t cell_axes;
+    float cell_scale[3], cell_off[3];
+    float ubox[6];
     const float4* mat_color;    // n_padded x (r, g, b, param)
     const int32_t* mat_type;    // n_padded
     const int32_t* orig;        // n_padded: caller's sphere index of the slot, INT_MAX for pad slots

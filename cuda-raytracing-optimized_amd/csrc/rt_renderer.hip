@@ -104,7 +104,8 @@ struct RenderContext {
     float cull_c[3] = { 0, 0, 0 }, cull_radius = 0, cull_k1 = 0, cull_k2 = 0, cull_k3 = 0, cull_coord_max = 0, pair_k0 = 0;
     int box_shared_axis = 0;
     int cell_on = 0;
-    float cell_scale[2] = { 0, 0 }, cell_off[2] = { 0, 0 };
+    float cell_scale[3] = { 0, 0, 0 }, cell_off[3] = { 0, 0, 0 }, ubox[6] = { 0, 0, 0, 0, 0, 0 };
+    int cell_axes = 0;
     float box_shared_lo = 0, box_shared_hi = 0;
     std::vector<int32_t> h_orig;        // slot -> caller's sphere index (INT_MAX = pad)
     std::vector<int32_t> h_slot_of;     // caller's sphere index -> slot
@@ -403,38 +404,40 @@ void build_sphere_groups(const rt_sphere* spheres, const rt_material* materials,
     }
     c.box_shared_axis = 0;
     for (int a = 2; a >= 0; a--) if (n_boxes > 0 && shared_ok[a]) { c.box_shared_axis = a + 1; c.box_shared_lo = shared_lo[a]; c.box_shared_hi = shared_hi[a]; }
-    // Cell tables (rt_params.h, group_needs_cells): for scenes of <= 32 small groups whose boxes share an axis.  Bit g of a word = small group g.
+    // Cell tables (rt_params.h, group_needs_cells): for scenes of up to 32 x kCellWordsMax groups, on all three axes.  Bit g of a word = small group g.
     // begins[c] = boxes with lo <= upper edge of cell c, ends[c] = boxes with hi >= lower edge of cell c, both with a slack of kCellSlack cells for
     // the rounding of the device's cell index (x * scale + off in fp32 with |index| <= kCellCount: off by < 2e-5 cells); the last begins-word and the
     // first ends-word hold every box, so that a coordinate beyond the tables' extent - clamped to the first / last cell on the device - rejects
-    // nothing it should not.
+    // nothing it should not.  An axis on which every box has the same extent (spheres resting on a plane: the vertical one) gets no bit in cell_axes:
+    // its table could not reject anything.  ubox = the union of the boxes, to which the kernel clips the ray before it looks anything up.
     constexpr double kCellSlack = 1.0e-3;
     c.cell_on = 0;
+    c.cell_axes = 0;
     const int cell_words = rt_cell_words(c.n_groups);
-    c.h_groups.resize((size_t)c.n_groups * 3 + (size_t)kCellCount * cell_words, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    if (c.box_shared_axis == 2 && n_boxes > 0 && cell_words > 0) {      // (the kernel instantiates the prefilter for a shared y axis only: spheres on a horizontal plane)
-        const int ax = c.box_shared_axis - 1;
-        const int axes[2] = { (ax + 1) % 3, (ax + 2) % 3 };
+    c.h_groups.resize((size_t)c.n_groups * 3 + (size_t)rt_cell_f4(c.n_groups), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int a = 0; a < 3; a++) { c.ubox[a] = 0.0f; c.ubox[3 + a] = 0.0f; c.cell_scale[a] = 0.0f; c.cell_off[a] = 0.0f; }
+    if (n_boxes > 0 && cell_words > 0) {
         const int W = cell_words;
         uint32_t* tab = reinterpret_cast<uint32_t*>(c.h_groups.data() + (size_t)c.n_groups * 3);
         std::vector<char> real(c.n_groups, 0);
         for (int g = n_big_groups; g < c.n_groups; g++) real[g] = c.h_groups[3 * g].x <= c.h_groups[3 * g].y;
         bool ok = true;
-        for (int q = 0; q < 2 && ok; q++) {
-            const int a = axes[q];
+        for (int a = 0; a < 3 && ok; a++) {
             double amin = 1e300, amax = -1e300;
             for (int g = n_big_groups; g < c.n_groups; g++) {
                 if (!real[g]) continue;
                 amin = std::min(amin, (double)c.h_groups[3 * g + a].x);
                 amax = std::max(amax, (double)c.h_groups[3 * g + a].y);
             }
+            c.ubox[a] = (float)amin; c.ubox[3 + a] = (float)amax;      // (box coordinates are floats: exact)
             const double w = (amax - amin) / kCellCount;
             if (!(w > 1e-30) || !std::isfinite(w) || !std::isfinite(1.0 / w) || !std::isfinite(amin / w)) { ok = false; break; }
-            c.cell_scale[q] = (float)(1.0 / w);
-            c.cell_off[q] = (float)(-amin / w);
+            c.cell_scale[a] = (float)(1.0 / w);
+            c.cell_off[a] = (float)(-amin / w);
+            if (!shared_ok[a]) c.cell_axes |= 1 << a;
             for (int cell = 0; cell < kCellCount; cell++) {
-                uint32_t* begins = tab + ((size_t)(2 * q) * kCellCount + cell) * W;
-                uint32_t* ends = tab + ((size_t)(2 * q + 1) * kCellCount + cell) * W;
+                uint32_t* begins = tab + ((size_t)(2 * a) * kCellCount + cell) * W;
+                uint32_t* ends = tab + ((size_t)(2 * a + 1) * kCellCount + cell) * W;
                 for (int g = n_big_groups; g < c.n_groups; g++) {
                     if (!real[g]) continue;
                     const int k = g - n_big_groups;
@@ -687,7 +690,8 @@ void runRenderer(int ns, int tx, int ty) {
             p.groups = d.d_groups; p.orig = d.d_orig; p.slot_of = d.d_slot_of;
             p.cull_cx = c.cull_c[0]; p.cull_cy = c.cull_c[1]; p.cull_cz = c.cull_c[2]; p.cull_radius = c.cull_radius;
             p.cull_k1 = c.cull_k1; p.cull_k2 = c.cull_k2; p.cull_k3 = c.cull_k3; p.cull_coord_max = c.cull_coord_max; p.pair_k0 = c.pair_k0; p.box_shared_axis = c.box_shared_axis; p.box_shared_lo = c.box_shared_lo; p.box_shared_hi = c.box_shared_hi;
-            p.cell_on = c.cell_on; for (int q = 0; q < 2; q++) { p.cell_scale[q] = c.cell_scale[q]; p.cell_off[q] = c.cell_off[q]; }
+            p.cell_on = c.cell_on; p.cell_axes = c.cell_axes;
+            for (int q = 0; q < 3; q++) { p.cell_scale[q] = c.cell_scale[q]; p.cell_off[q] = c.cell_off[q]; p.ubox[q] = c.ubox[q]; p.ubox[3 + q] = c.ubox[3 + q]; }
             p.fb = d.d_fb; p.part = part;
             p.sky = c.opt.sky; p.rr = c.opt.rr; p.rng_mode = c.opt.rng; p.t_min = c.opt.t_min;
             p.counters = c.opt.counters ? d.d_counters : nullptr;

@@ -210,6 +210,37 @@ def test_arbitrary_sphere_scenes_bit_exact(rt, O, n, big, dup):
         got, st = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 20, counters=1, variant=variant)
         assert np.array_equal(_bits(got), _bits(ref)), (variant, np.count_nonzero(_bits(got) != _bits(ref)))
         assert st.rays == cnt.rays
+    # without the counters the launcher takes the PRODUCTION instantiations (the counting one is the general kernel): the lean kernels where the scene
+    # allows them (basic materials, one pass of <= 32 groups behind the 3-axis cell tables)
+    got, _ = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 20)
+    assert np.array_equal(_bits(got), _bits(ref)), np.count_nonzero(_bits(got) != _bits(ref))
+
+
+@pytest.mark.parametrize("n,shape", [(488, "volume"), (700, "volume"), (900, "volume"), (1500, "volume"), (488, "plane"), (700, "plane"), (900, "plane"),
+                                     (1500, "plane"), (300, "wall"), (200, "column"), (520, "cluster")])
+def test_scene_shapes_3d_and_plane_production_kernels(rt, O, n, shape):
+    """scenes that are NOT the cover image - small spheres scattered in a volume (no shared slab: the 3-axis cell tables), on a plane, on a
+    vertical wall (shared x), in a thin column, in one tight cluster far from a second one - at sizes across the one-pass / multi-pass and full-copy / hybrid
+    boundaries, rendered by the production instantiations (no counters) on the two-dispatch path (8 spp) and the single dispatch (2 spp), against the oracle."""
+    rng = np.random.default_rng(4000 + n)
+    sp = np.zeros(n, rt.sphere_dtype); mt = np.zeros(n, rt.material_dtype)
+    c = rng.uniform(-12, 12, (n, 3))
+    if shape == "volume": c[:, 1] = rng.uniform(0.3, 7.0, n)
+    elif shape == "plane": c[:, 1] = 0.2
+    elif shape == "wall": c[:, 0] = 1.0; c[:, 1] = rng.uniform(0.3, 9.0, n)
+    elif shape == "column": c[:, 0] = rng.uniform(-0.3, 0.3, n); c[:, 2] = rng.uniform(-0.3, 0.3, n); c[:, 1] = rng.uniform(0.3, 12.0, n)
+    else: c = np.where((np.arange(n) % 2 == 0)[:, None], rng.uniform(-1, 1, (n, 3)) + (0, 1.5, 0), rng.uniform(-1, 1, (n, 3)) + (30, 20, -25))
+    sp["center"] = c
+    sp["radius"] = 0.2 if shape == "plane" else rng.uniform(0.1, 0.3, n)
+    sp["center"][0] = (0, -1000, 0); sp["radius"][0] = 1000
+    mt["type"] = rng.choice([0, 0, 0, 0, 1, 2], n); mt["color"] = rng.uniform(0.2, 1, (n, 3)); mt["param"] = np.where(mt["type"] == 2, 1.5, 0.2); mt["texId"] = -1
+    mt["type"][0] = 0
+    nx, ny = 80, 48
+    cam = rt.make_camera((13, 2, 3), (0, 0.5, 0), (0, 1, 0), 30.0, nx / ny, 0.1, 10.0)
+    for ns in (8, 2):
+        ref, _ = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50)
+        got, _ = _render_gpu(rt, sp, mt, cam, nx, ny, ns, 50)
+        assert np.array_equal(_bits(got), _bits(ref)), (ns, np.count_nonzero(_bits(got) != _bits(ref)))
 
 
 @pytest.mark.parametrize("axis", [0, 1, 2])
