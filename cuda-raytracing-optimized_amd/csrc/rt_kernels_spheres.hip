@@ -1353,7 +1353,7 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
 //   SCENE    where the scene is read from (stage_scene): 0 = an LDS copy, 1 = global memory, 2 = test data in the LDS, hit data in global memory
 //   LEAN     bit 0: the scene's materials are the three basic ones: lean shading (material_scatter<BASIC>); bit 1: its small groups take ONE list per ray batch
 //            behind the cell-table prefilter (scan_pairs<OP>: at most 32 groups, 64 with bit 4, 128 with bit 5); bit 3: that prefilter is the general 3-axis one (no shared
-//            vertical extent: spheres scattered in space); only with SCENE = 0 and without DBG.  Bits 0 + 1 need ~100 VGPRs instead of 128; bit 2 (with
+//            vertical extent: spheres scattered in space); only with SCENE = 0 (a few kinds also with SCENE = 2) and without DBG.  Bits 0 + 1 need ~100 VGPRs instead of 128; bit 2 (with
 //            both): compiled for SIX waves per SIMD (80 VGPRs, ~20 of them spilled) and launched as two 12-wave workgroups per CU - see launch_spheres for when
 template <int PHASE, int CLS, bool CHUNKED, bool DBG, int SCENE = 0, int LEAN = 0>
 __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres_queue(const RtSphereParams P, uint32_t stride, int cfg, int chain_cfg, int caps) {
@@ -1771,6 +1771,14 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
         default: break;
         }
     }
+    if (SCENE == 2 && !CHUNKED) {                                    // the hybrid scene copy (hit data in global memory: ~1500-3400 spheres)
+        switch (g_lean) {
+        case 1:  return go(k_render_spheres_queue<PHASE, CLS, false, false, 2, 1>);
+        case 35: return go(k_render_spheres_queue<PHASE, CLS, false, false, 2, 35>);
+        case 43: return go(k_render_spheres_queue<PHASE, CLS, false, false, 2, 43>);
+        default: break;
+        }
+    }
     return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, false, SCENE>);
 }
 
@@ -1841,8 +1849,12 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     bool hybrid = false;
     if (kind == 0 && !p.global_scene) {
         if (lds_bytes(p.n_padded, p.n, false, 0, 16, lean_list) <= kLdsPerCu) { hybrid = false; waves = 16; }
-        else if (lds_bytes(p.n_padded, p.n, false, 2, 16) <= kLdsPerCu) { hybrid = true; waves = 16; g_lean = 0; }
-        else { hybrid = true; waves = 8; g_lean = 0; }
+        else {                                                                   // hybrid: the lean kinds built for it are 1 and the four-word lists
+            hybrid = true;
+            if (g_lean != 1 && (g_lean & 32) == 0) g_lean &= 1;
+            if (lds_bytes(p.n_padded, p.n, false, 2, 16, (g_lean & 2) != 0) <= kLdsPerCu) waves = 16;
+            else { waves = 8; }
+        }
     }
     if ((g_lean & 0x32) == 2 && lean6_pixels > 0 && (long long)p.nx * p.part.local_rows >= lean6_pixels &&
         2 * (lds_bytes(p.n_padded, p.n, false, 0, 12, true) + kStaticLds) <= (size_t)160 * 1024) { g_lean |= 4; waves = 12; lean_wgs = 2; }
@@ -1887,7 +1899,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     int order_mode = (variant >> 24) & 3;
     // Scenes whose hit data (hybrid copy) or whole scene (global) is read from global memory: the scattered single dispatch beats the cost-ordered two
     // dispatches (tools/sweep_scene_sizes.py, 1200x800x50, 16-wave workgroups: 1500 spheres 2819 against 2751, 2000: 2113 / 1696, 2600: 1812 / 1149).
-    if (order_mode == 0 && (hybrid || p.global_scene)) order_mode = 2;
+    static const bool hybrid_two = getenv("RT_HYBRID_TWO") && getenv("RT_HYBRID_TWO")[0] == '1';      // A/B: the cost-ordered two dispatches for the hybrid copy too
+    if (order_mode == 0 && ((hybrid && !hybrid_two) || p.global_scene)) order_mode = 2;
     if (order_mode != 1 && total_px > 64) {
         auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
         unsigned long long cand = (unsigned long long)((double)total_px * 0.6180339887) | 1ull;

@@ -3,16 +3,17 @@
 24 x 24 field ("plane": the benchmark's shape, every group box shares its vertical extent) or scattered in the 24 x 7 x 24 volume above it ("volume": no
 shared slab; the 3-axis cell tables).  The field does not grow with n, so the scene gets DENSER: a sample traces more rays - the table prints rays per
 sample (device counters) and Mrays/s beside Msamples/s, which is what compares kernels across sizes.  Work orders: the default (cost-ordered two dispatches
-where the launcher allows them) and the scattered single dispatch."""
+where the launcher allows them) and the scattered single dispatch.  SWEEP_NX / SWEEP_NY / SWEEP_SPP / SWEEP_N override the frame and the sizes
+(a 1200x800 frame at 50 spp ends with its slowest pixels, which get slower as the field gets denser; 2560x1440 at 16 spp is bound by throughput)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import cuda_raytracing_optimized_amd as rt
 
 shape = sys.argv[1] if len(sys.argv) > 1 else "plane"
-NX, NY, SPP = 1200, 800, 50
+NX, NY, SPP = int(os.environ.get("SWEEP_NX", 1200)), int(os.environ.get("SWEEP_NY", 800)), int(os.environ.get("SWEEP_SPP", 50))
 _, _, cam = rt.scene_random_spheres(NX, NY)
-for n in (300, 488, 700, 900, 1100, 1500, 2000, 2600, 4000):
+for n in [int(x) for x in os.environ.get("SWEEP_N", "300,488,700,900,1100,1500,2000,2600,4000").split(",")]:
     rng = np.random.default_rng(3)
     sp = np.zeros(n, rt.sphere_dtype); mt = np.zeros(n, rt.material_dtype)
     if shape == "plane":
