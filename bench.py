@@ -245,9 +245,10 @@ def mesh_roofline(job, world, traffic=None):
          "kernel": "k_render_mesh_queue", "kernel_ms_avg": job["kernel_ms"],
          "per_sample": {k: c[k] / job["samples"] for k in ("rays", "shadow_rays", "node_visits", "prim_tests")},
          "note": "algorithmic gather bytes = 48 x node visits + 64 x triangle tests + 64 x rays (device counters, equal to the oracle's) / kernel time; "
-                 "peak = chip-wide L2-served row-gather rate (MI355X_MICROARCH.md, 'Indexed rows'). The rays touch 1.5 MB of node records and "
-                 "5.2 MB of triangle slots: more than one XCD's 4 MB L2, the rest is served by the Infinity Cache - `traffic` (FETCH_SIZE + WRITE_SIZE, "
-                 "the bytes that leave L2) is compared with THESE gather bytes, not with the framebuffer"}
+                 "peak = chip-wide L2-served row-gather rate (MI355X_MICROARCH.md, 'Indexed rows': measured there on 1,152-byte rows, a generous "
+                 "denominator for 48-byte records). The rays touch 1.5 MB of node records and 1.7 MB of compact leaf records (48 B per real triangle): "
+                 "one XCD's 4 MB L2 holds them - `traffic` (2 x FETCH_SIZE + WRITE_SIZE, the bytes that leave L2) is compared with THESE gather bytes, "
+                 "not with the framebuffer"}
     r.update(traffic or {"traffic": None})
     if r.get("traffic"):
         r["traffic_over_algorithmic"] = r["traffic"] / by
@@ -407,7 +408,8 @@ def main():
             # C3: the same frame at 1000 spp
             j3 = run_job(hip, comm, WORKLOADS["C3"], 2, 1, tag, count_spp=8, warmup_spp=16)
             others["C3"] = brief(j3, {"workload": WORKLOADS["C3"]["name"] + ", " + mode,
-                                      "roofline": {k: v for k, v in sphere_roofline(j3, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic")}})
+                                      "roofline": {k: v for k, v in sphere_roofline(j3, 1, committed_traffic("C3", 1200 * 800 * 12) if default_mode else None).items()
+                                                   if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic", "traffic_over_algorithmic", "traffic_source")}})
             # C4: triangle mesh + BVH through the reference's own entry point
             j4 = run_job(HipBackend(args.fp, "reference", 0), comm, WORKLOADS["C4"], 2, 1, tag, count_spp=4, warmup_spp=16)
             w4 = WORKLOADS["C4"]
@@ -416,7 +418,8 @@ def main():
             # C5's workload on this one GPU (the denominator of the N > 1 strong-scaling lines)
             j5 = run_job(hip, comm, WORKLOADS["C5"], 1, 1, tag, count_spp=4, warmup_spp=16)
             others["C5_one_gpu"] = brief(j5, {"workload": WORKLOADS["C5"]["name"] + ", " + mode + "; the whole frame on ONE GPU",
-                                              "roofline": {k: v for k, v in sphere_roofline(j5, 1).items() if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic")}})
+                                              "roofline": {k: v for k, v in sphere_roofline(j5, 1, committed_traffic("C5", 3840 * 2160 * 12) if default_mode else None).items()
+                                                           if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic", "traffic_over_algorithmic", "traffic_source")}})
     else:
         w = with_overrides(WORKLOADS["C5"])
         job = run_job(hip, comm, w, args.steps, args.warmup, tag, count_spp=4, warmup_spp=16, keep_image=True)

@@ -3,19 +3,20 @@
 // Replaces /root/reference/kernels.cu:535-569 (render), :396-533 (color), :325-360 (hit),
 // :296-323 (hitMesh), :154-224 (hitBvh, DUAL_NODES), :148-152 (pop_bitstack) and :363-393
 // (generateShadowRay), plus the primitive tests of intersections.h:7-41,54-104.
-// Compiled twice (see rt_kernels_spheres.hip): PARITY (-ffp-contract=off, bit-exact vs the
-// oracle up to libm differences in cos/sin) and FAST (FMA contraction).
+// Compiled twice (see rt_kernels_spheres.hip): PARITY (-ffp-contract=off: bit-exact vs the oracle, light sampling included - cosf / sinf / powf are
+// glibc's algorithms restated, rt_glibc_sincosf.h / rt_glibc_powf.h) and FAST (FMA contraction).
 //
 // MI355X design:
-//   * one lane = one pixel + its RNG stream; flattened loop with in-lane sample refill;
-//   * BVH child pairs (48 B) are fetched with three plain global_load_dwordx4 from the heap-indexed
-//     node array (the reference used a 1D texture object: kernels.cu:166-173, 590-605); the ~25 MB
-//     working set is L2 / Infinity-Cache resident;
-//   * 1/direction is computed once per ray instead of per box per axis (intersections.h:28) —
-//     the quotient is the same value each time, so this is bit-identical;
-//   * the slab test runs all three axes branch-free: t_min only grows and t_max only shrinks, so a
-//     final `t_max < t_min` equals the reference's per-axis early-out;
-//   * triangles are 64-byte records read as four dwordx4.
+//   * one lane = one pixel + its RNG stream; persistent waves, a pixel queue, and a per-lane ray-JOB state machine (closest-hit or shadow ray, same code):
+//     a wave alternates between TRAVERSE (node steps for the lanes at an internal node, or (ray, triangle) pair rounds for the lanes waiting at a leaf)
+//     and PROCESS (scatter, next-event estimation, Russian roulette in the reference's order for the lanes whose traversal ended);
+//   * BVH child pairs are read from axis-grouped 96-byte records (per axis the four planes in both orders: the `if (invD < 0) swap` of
+//     intersections.h:30 is a choice of address), three global_load_dwordx4 per node visit (the reference used a 1D texture object: kernels.cu:166-173);
+//   * leaves are read as compact 48-byte records (v0 and the two edges, rounded as intersections.h:56-57 rounds them; the count of real triangles per
+//     leaf in the LDS): 1.5 MB of node records + 1.7 MB of leaf records touched per frame of the benchmark tree - one XCD's L2 holds them;
+//   * 1/direction is computed once per ray instead of per box per axis (intersections.h:28) - the same quotient each time, so bit-identical; the slab
+//     test runs all three axes branch-free (t_min only grows, t_max only shrinks: the final `t_max < t_min` equals the per-axis early-out);
+//   * a lean instantiation (template LEAN) for untextured scenes of the three basic materials: fewer registers, no (u, v) through the traversal.
 #include "rt_device.h"
 #include "rt_params.h"
 
@@ -536,8 +537,8 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                     need_sample = true;
                 } else {
                     const f3 out = col / (float)P.ns;                // kernels.cu:568
-                    float* dst = fbf + ((size_t)lr * P.nx + pi) * 3;
-                    dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+                    // one 12-byte store (global_store_dwordx3): a lane finishes its pixel on its own, three dword stores are three partial-sector writes
+                    *reinterpret_cast<float3*>(fbf + ((size_t)lr * P.nx + pi) * 3) = make_float3(out.x, out.y, out.z);
                     have_pixel = false;
                 }
             }
@@ -880,7 +881,8 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
     uint32_t stride = 1;
-    if (total_px > 64) {
+    static const bool tile_order = getenv("RT_MESH_ORDER") && getenv("RT_MESH_ORDER")[0] == 't';       // A/B: tile-major pixel order (stride 1)
+    if (total_px > 64 && !tile_order) {
         auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
         unsigned long long cand = (unsigned long long)((double)total_px * 0.6180339887) | 1ull;
         while (gcd(cand, (unsigned long long)total_px) != 1ull) cand += 2;

@@ -57,6 +57,10 @@ using namespace rtd;
 
 namespace {
 
+#ifndef RT_MID_WAVES
+#define RT_MID_WAVES 0      // middle tier: waves per workgroup (0 = off) and pixels per such wave
+#define RT_MID_CAP 16
+#endif
 #ifndef RT_BOX_CUT
 #define RT_BOX_CUT 12       // group_needs_cells: the per-lane box loop stops when fewer lanes than this still have candidates (A/B on C5 at 256 spp, profiles/r04_ab_basic_c5.txt:
                             // 1 (never): 10870, 8: 10930, 12: 10945, 20: 10945 Msamples/s)
@@ -1396,6 +1400,11 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
         if (nA > 0u) spread -= ((gridDim.x + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u;
         s_q[0] = nA; s_q[1] = n0; s_q[2] = total_px * (CHUNKED ? (uint32_t)P.chunks : 1u); s_q[3] = spread;
         s_q[4] = (n0 > 0u && n0 <= spread && (spread - n0) <= n_rest) ? 1u : 0u;
+        // Middle tier (caps bits 16..19 = waves per workgroup, 20..27 = pixels such a wave holds; CLS = 2 only): the heavy lists are not spread over the normal
+        // waves but served, from their own counter (P.queue[2]), by "middle" waves that hold only a few pixels - see the role comment below.  The general
+        // queue is then the rest lists alone.
+        s_q[5] = 0u;
+        if (CLS == 2 && ((caps >> 16) & 0xF) != 0 && n0 > 0u) { s_q[5] = 1u; s_q[2] = n_rest; s_q[4] = 0u; }
     }
     __syncthreads();
     // Chain waves.  A lane that is not boosted advances ONE ray per wave iteration, and an iteration takes 3-4 us for <= 4
@@ -1406,8 +1415,14 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
     // priority, and the longest chain is over after 15 ms.  When the chain lists are empty the wave becomes a normal wave
     // (role 2: general queue, all 64 lanes), but keeps the cap for as long as it still holds a chain pixel.
     // (Tried and dropped: half-occupied "medium" waves for the heavy lists - what they gain in the tail they lose in throughput.)
+    // Middle waves (role 1; round 4): pixels of 6-12 rays per sample (the heavy lists) are too many for the chain waves and too long for a dense wave - a lane
+    // of a dense wave advances one ray per ~13 us iteration, a 100-spp pixel of 800 rays ends after 10 ms whenever it starts, and the frame with it.  A wave that
+    // holds only `mid_cap` pixels runs the same dense form at about half the iteration time (the per-lane phases cost what they cost, the pair rounds shrink
+    // with the rays): such pixels end in half the time for ~2.5x the cost per ray, on a few per cent of the frame's rays.
     int role = 2;
     if (CLS == 2 && s_q[0] > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
+    else if (CLS == 2 && s_q[5] != 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) + ((caps >> 16) & 0xF)) role = 1;
+    const int mid_cap = (caps >> 20) & 0xFF;
     int ccls = 7;                       // chain list (0 .. kChainClasses - 1) the lane's pixel came from (fetched while the wave had role 0), 7 = none.  A wave that
                                         // holds a pixel of list c holds at most caps[c] pixels (4 bits each)
 
@@ -1502,7 +1517,8 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
             // live-lane cap of this wave: by its role and by the tiers of the pixels it still holds
             const unsigned long long live_m = __ballot(have_pixel);
             int cap = 64;
-            if (CLS == 2 && (role == 0 || __ballot(have_pixel && ccls < 7) != 0ull)) {
+            if (CLS == 2 && (role == 1 || __ballot(have_pixel && ccls == 6) != 0ull)) cap = mid_cap;        // a middle wave, or a wave that still holds a middle-tier pixel
+            if (CLS == 2 && (role == 0 || __ballot(have_pixel && ccls < 6) != 0ull)) {
                 cap = (chain_cfg >> 12) & 0xF;
                 if (__ballot(have_pixel && ccls == 2) != 0ull) cap = min(cap, (caps >> 8) & 0xF);
                 if (__ballot(have_pixel && ccls == 1) != 0ull) cap = min(cap, (caps >> 4) & 0xF);
@@ -1524,9 +1540,9 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
             if (pool_next >= pool_end) {
                 // (PHASE 2, experiments: cfg bits 3..7 x 4 = positions a normal wave reserves at least per grab)
                 const uint32_t grab = (CHUNKED || PHASE == 1) ? max(cnt, 128u) : ((PHASE == 2 && role == 2) ? max(cnt, (uint32_t)((cfg >> 3) & 0x1F) * 4u) : cnt);
-                const uint32_t limit = role == 0 ? s_q[0] : total;
+                const uint32_t limit = role == 0 ? s_q[0] : (role == 1 ? s_q[1] : total);
                 uint32_t b = 0;
-                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : 0), grab);
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : (role == 1 ? 2 : 0)), grab);
                 b = __builtin_amdgcn_readfirstlane(b);
                 if (b >= limit) {
                     if (role < 2) { role = 2; continue; }            // this wave's lists are empty: a normal wave from now on
@@ -1557,6 +1573,8 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
                     // else; position p is a heavy-list position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
                     uint32_t q;                                      // position in the concatenation of all lists
                     if (role == 0) q = pos;
+                    else if (role == 1) q = s_q[0] + pos;                                    // the heavy lists, in order (longest estimates first)
+                    else if (CLS == 2 && s_q[5] != 0u) q = s_q[0] + s_q[1] + pos;           // middle tier on: the general queue is the rest lists
                     else {
                         const uint32_t nA = s_q[0], n0 = s_q[1], spread = s_q[3];
                         const bool spread_ok = s_q[4] != 0u;
@@ -1616,6 +1634,7 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
                     have_pixel = true;
                     ccls = 7;
                     if (CLS == 2 && role == 0) { ccls = 0; for (int k = 1; k < kChainClasses; k++) if (pos >= s_cls_pos[k]) ccls = k; }
+                    if (CLS == 2 && role == 1) ccls = 6;
                 }
             }
         }
@@ -1635,7 +1654,8 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
         // per full iteration; it gets `boost` extra rays per iteration, traced in the cheap sparse form (all 64 lanes on
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
         // (One call site for both: the scan is large and must not be inlined twice.)
-        const int steps = (boost > 0 && __popcll(live_now) > sparse_max) ? 1 + boost : 1;
+        // (a wave of the middle tier is fast already: no boost steps while it holds such a pixel)
+        const int steps = (boost > 0 && __popcll(live_now) > sparse_max && !(CLS == 2 && s_q[5] != 0u && __ballot(have_pixel && ccls == 6) != 0ull)) ? 1 + boost : 1;
         for (int x = 0; x < steps; x++) {
             bool sel = have_pixel;
             if (x > 0) {
@@ -1917,6 +1937,12 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     // basin: 768 waves, list 0 from 20..26 rays per sample, 2..4 pixels for the other lists all within 0.5 %; 1024 waves -2 %, list 0 from 30: -6 %).
     int chain_cfg = 1 | ((waves == 16 ? 3 : (waves >= 10 ? 2 : 1)) << 8) | (kSparseRays << 12) | (8 << 16) | (kChainClasses << 24);
     int caps = 1 | (4 << 4) | (4 << 8) | (4 << 12);     // pixels a chain wave holds while one of them comes from chain list 0 / 1 / 2 / 3
+    static const char* mid_env = getenv("RT_MID");       // "waves per workgroup,pixels per wave" of the middle tier (k_render_spheres_queue, role 1); 0 = off
+    int mid_waves = RT_MID_WAVES, mid_cap = RT_MID_CAP;
+    if (mid_env) sscanf(mid_env, "%d,%d", &mid_waves, &mid_cap);
+    if (mid_waves < 0 || mid_waves > 12 || mid_cap < 1 || mid_cap > 64) return hipErrorInvalidValue;
+    const int caps_mid = (mid_waves << 16) | (mid_cap << 20);
+    caps |= caps_mid;
     int cfg = cull | (boost << 8) | (sparse_max << 16);
     static const bool chain_single = !(getenv("RT_CHAIN_SINGLE") && getenv("RT_CHAIN_SINGLE")[0] == '0');  // chain waves grab one pixel at a time
     static const bool single_ray = !(getenv("RT_SINGLE_RAY") && getenv("RT_SINGLE_RAY")[0] == '0');          // scan_single for waves with one live ray
@@ -1939,7 +1965,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
             return hipErrorInvalidValue;
         }
         chain_cfg = a | (b << 8) | (f << 12) | (c << 16) | (d << 24);
-        caps = g | (g1 << 4) | (g2 << 8) | (f << 12);
+        caps = g | (g1 << 4) | (g2 << 8) | (f << 12) | caps_mid;
         cfg = cull | (e2 << 8) | (sparse_max << 16) | (chain_single ? 2 : 0) | (single_ray ? 4 : 0) | (((pool_env / 4) & 0x1F) << 3) | (dbg_light ? (1 << 29) : 0);
     }
     const unsigned nb = (unsigned)blocks;

@@ -4,7 +4,9 @@
 TAG=${1:-r03}
 O=gpurun_out
 bash tools/measure_traffic.sh $TAG > $O/${TAG}_measure.log 2>&1 || exit 1
-cp $O/traffic.json $O/${TAG}_C2_summary.txt $O/${TAG}_C4_summary.txt profiles/
+cp $O/traffic.json $O/${TAG}_C2_summary.txt $O/${TAG}_C4_summary.txt $O/${TAG}_C3_summary.txt $O/${TAG}_C5_summary.txt profiles/
+{ bash tools/kernel_resources.sh spheres parity; bash tools/kernel_resources.sh mesh parity; } > profiles/${TAG}_kernel_resources.txt 2>&1      # the code objects of THESE sources
+cp profiles/${TAG}_kernel_resources.txt $O/
 timeout -k 10 900 python3 -m pytest tests -m gpu -q -x > $O/${TAG}_gpu_tests_final.txt 2>&1; tail -2 $O/${TAG}_gpu_tests_final.txt
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_parity.json 2> $O/${TAG}_bench_parity.err || exit 1
 python3 bench.py --no-cpu-baseline --fp fast > $O/${TAG}_bench_fpfast.json 2>/dev/null

@@ -20,7 +20,7 @@ def rows(d, pattern):
                 yield r
 
 
-for W, per_frame in (("C2", 2), ("C4", 1)):
+for W, per_frame in (("C2", 2), ("C4", 1), ("C3", 2), ("C5", 2)):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{W}")
     if not os.path.isdir(d):
         continue
