@@ -1761,6 +1761,7 @@ static hipError_t launch_queue_kernel_global(const RtSphereParams& q, unsigned b
 
 static int g_queue_threads = kThreads;      // workgroup size of the persistent kernel for the scene being launched (launch_spheres: 16 waves, or 8 when only that fits)
 
+static int g_lean_dbg = 0;                  // the kind the scene would take without the diagnostics (time lines of the production kernel)
 static int g_lean = 0;                      // LEAN bits of the instantiation launch_spheres chose for the scene being launched (0 = the general kernel)
 
 template <int PHASE, int CLS, bool CHUNKED, int SCENE>
@@ -1776,6 +1777,8 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(g_queue_threads), lds, stream, q, stride, cfg, chain_cfg, caps);
         return hipGetLastError();
     };
+    // (time lines of the PRODUCTION kernel of the benchmark scene - RT_WAVE_DEBUG with RT_WAVE_DEBUG_LIGHT=1, no counters: the lean kind 3 with the stamps)
+    if (counting && q.counters == nullptr && SCENE == 0 && !CHUNKED && PHASE != 0 && g_lean_dbg == 3) return go(k_render_spheres_queue<PHASE, CLS, false, true, 0, 3>);
     if (counting) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>);
     if (SCENE == 0 && !CHUNKED) {                                    // (the sample chunks of the counter stream take the general kernel)
         switch (g_lean) {
@@ -1850,7 +1853,8 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     const bool counting = p.wave_dbg != nullptr || p.counters != nullptr;
     g_lean = 0;
     int lean_wgs = 1;
-    if (kind == 0 && !p.global_scene && !counting && p.basic_materials && basic_env && p.chunks == 1) {
+    g_lean_dbg = 0;
+    if (kind == 0 && !p.global_scene && p.basic_materials && basic_env && p.chunks == 1) {
         const int n_small_groups = p.n_groups - p.n_big_groups;
         g_lean = 1;
         if (cull && p.cell_on != 0 && n_small_groups >= 1 && n_small_groups <= 128 && onepass_env) {
@@ -1860,6 +1864,11 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
             if (p.box_shared_axis != 2) g_lean |= 8;                             // no shared vertical extent: the 3-axis prefilter
         }
     }
+    static const bool dbg_light_env = getenv("RT_WAVE_DEBUG_LIGHT") && getenv("RT_WAVE_DEBUG_LIGHT")[0] == '1';
+    // (only a frame that takes the two cost-ordered dispatches: its two kernels are the ones instantiated with the stamps)
+    const bool two_phase_frame = ((variant >> 24) & 3) == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8 &&
+                                 p.nx <= 65535 && p.part.local_rows <= 65535;
+    if (counting) { g_lean_dbg = (g_lean == 3 && p.counters == nullptr && dbg_light_env && two_phase_frame) ? 3 : 0; g_lean = g_lean_dbg == 3 ? 3 : 0; }
     const bool lean_list = (g_lean & 2) != 0;                                    // (the smaller per-wave scratch)
     // The persistent kernel's workgroup is a whole CU's worth of waves (16: the launch bound's 4 per SIMD) around ONE scene copy - 88 KB of per-wave scratch (68
     // in the one-list kernels) leave 72 (92) KB for the scene: the full copy up to ~1200 (1500) spheres (60 bytes per sphere), the hybrid one (what a sphere TEST
@@ -1948,7 +1957,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     static const bool single_ray = !(getenv("RT_SINGLE_RAY") && getenv("RT_SINGLE_RAY")[0] == '0');          // scan_single for waves with one live ray
     // phase 2: a normal wave reserves at least 8 queue positions per grab (one atomic round trip per ~6 finished pixels instead of per ~1: +1.3 % on C2;
     // 16 and more hoard pixels at the end of the frame and lose: 8 -> 7144, 16 -> 6616, 32 -> 6019 Msamples/s, profiles/r03_sweep_pool.txt)
-    static const int pool_env = getenv("RT_POOL") ? atoi(getenv("RT_POOL")) : 8;
+    static const int pool_env = getenv("RT_POOL") ? atoi(getenv("RT_POOL")) : 4;      // (round 4, lean kernel: 4 -> 8517, 8 -> 8420, 16 -> 8110 Msamples/s, profiles/r04_sweep_tune_c2.txt)
     if (chain_single) cfg |= 2;
     if (single_ray) cfg |= 4;
     cfg |= ((pool_env / 4) & 0x1F) << 3;

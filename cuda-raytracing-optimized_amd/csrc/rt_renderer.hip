@@ -726,7 +726,8 @@ void runRenderer(int ns, int tx, int ty) {
                 HIP_CHECK(hipHostGetDevicePointer(&dp, (void*)h_target, 0));
                 p.fb = reinterpret_cast<rt_vec3*>(dp);
                 p.fb_global_rows = 1;
-                p.poison_fb = 1;
+                static const bool poison_env = !(getenv("RT_FB_POISON") && getenv("RT_FB_POISON")[0] == '0');      // (experiment switch)
+                p.poison_fb = poison_env ? 1 : 0;
             }
             // the device copy of the parameter block (RtSphereParams::self): owned by this DeviceState, refreshed by every frame from a pinned
             // staging copy (runRenderer is synchronous: the previous frame's upload has completed)

@@ -1,5 +1,4 @@
-RT_MID=3,16 timeout -k 10 300 python3 -m pytest tests/test_gpu_parity_spheres.py tests/test_gpu_parity_configs.py -m gpu -q -x > gpurun_out/r04_t11_mid_tests.txt 2>&1; tail -3 gpurun_out/r04_t11_mid_tests.txt
-AB_STEPS=10 bash tools/ab2.sh 2 build/ab/op4.so build/ab/mid.so "build/ab/mid.so;RT_MID=2,16" "build/ab/mid.so;RT_MID=3,16" "build/ab/mid.so;RT_MID=4,16" "build/ab/mid.so;RT_MID=3,12" "build/ab/mid.so;RT_MID=3,24" "build/ab/mid.so;RT_MID=2,32" "build/ab/mid.so;RT_MID=4,8" "build/ab/mid.so;RT_MID=5,12" > gpurun_out/r04_sweep_mid_c2.txt 2>&1; cat gpurun_out/r04_sweep_mid_c2.txt
-AB_W=C3 AB_STEPS=2 bash tools/ab2.sh 1 build/ab/mid.so "build/ab/mid.so;RT_MID=3,16" "build/ab/mid.so;RT_MID=4,16" > gpurun_out/r04_sweep_mid_c3.txt 2>&1; cat gpurun_out/r04_sweep_mid_c3.txt
-bash tools/ab_mesh.sh 2 build/ab/cur.so > gpurun_out/r04_ab_mesh_order.txt 2>&1; RT_MESH_ORDER=t bash tools/ab_mesh.sh 2 build/ab/cur.so >> gpurun_out/r04_ab_mesh_order.txt 2>&1; cat gpurun_out/r04_ab_mesh_order.txt
-LT="8 12 16" MT="16 24 32" TRAV=0 bash tools/sweep_mesh.sh > gpurun_out/r04_sweep_mesh_lean.txt 2>&1; cat gpurun_out/r04_sweep_mesh_lean.txt
+timeout -k 10 400 python3 -m pytest tests/test_gpu_parity_spheres.py tests/test_gpu_parity_configs.py -m gpu -q -x > gpurun_out/r04_t12_fast_tests.txt 2>&1; tail -3 gpurun_out/r04_t12_fast_tests.txt
+AB_STEPS=10 bash tools/ab2.sh 3 build/ab/cur.so build/ab/fast.so > gpurun_out/r04_ab_fastpath_c2.txt 2>&1; cat gpurun_out/r04_ab_fastpath_c2.txt
+AB_W=C3 AB_STEPS=2 bash tools/ab2.sh 2 build/ab/cur.so build/ab/fast.so > gpurun_out/r04_ab_fastpath_c3.txt 2>&1; cat gpurun_out/r04_ab_fastpath_c3.txt
+AB_W=C5 AB_SPP=256 AB_STEPS=5 bash tools/ab2.sh 2 build/ab/cur.so build/ab/fast.so > gpurun_out/r04_ab_fastpath_c5.txt 2>&1; cat gpurun_out/r04_ab_fastpath_c5.txt
