@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/final_pass.sh <tag> — what profiles/ holds for the committed kernels, in ONE GPU call: the rocprofv3 passes (traffic.json keyed by the kernel source hash),
 # the GPU test suite, the contract bench line (which then finds the matching traffic.json), the other modes, and a two-rank rehearsal of the N > 1 path on the one GPU.
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out
 bash tools/measure_traffic.sh $TAG > $O/${TAG}_measure.log 2>&1 || exit 1
 cp $O/traffic.json $O/${TAG}_C2_summary.txt $O/${TAG}_C4_summary.txt $O/${TAG}_C3_summary.txt $O/${TAG}_C5_summary.txt profiles/
