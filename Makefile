@@ -13,7 +13,7 @@ CSRC     := $(PKG)/csrc
 HOST     := $(PKG)/host
 OBJ      := build/obj
 
-KERNEL_HDRS := $(CSRC)/rt_device.h $(CSRC)/rt_glibc_sincosf.h $(CSRC)/rt_glibc_powf.h $(CSRC)/rt_params.h include/rt_types.h
+KERNEL_HDRS := $(CSRC)/rt_device.h $(CSRC)/rt_div64.h $(CSRC)/rt_glibc_sincosf.h $(CSRC)/rt_glibc_powf.h $(CSRC)/rt_params.h include/rt_types.h
 
 all: $(PKG)/librt_mi355x.so $(PKG)/librt_host.so
 	$(MAKE) -C oracle

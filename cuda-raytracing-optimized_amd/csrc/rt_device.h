@@ -45,7 +45,34 @@ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + 
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }   // vec3.h:63
 __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }   // vec3.h:67
 __device__ __forceinline__ f3 operator*(float t, f3 a) { return { t * a.x, t * a.y, t * a.z }; }       // vec3.h:75,83
-__device__ __forceinline__ f3 operator/(f3 a, float t) { return { a.x / t, a.y / t, a.z / t }; }       // vec3.h:79
+// ---- IEEE division and square root through fp64 (rt_div64.h: the argument and the host twin) ------------------------------------------------
+// vec3 / float (vec3.h:79) and unit_vector (vec3.h:194): the same bits as the plain operators for ~16 / ~28 instead of ~33 / ~47 instructions, three call
+// sites per ray.  RT_DIV64=0 (A/B) and the FAST build keep the compiler's expansion.
+#ifndef RT_DIV64
+#define RT_DIV64 0          // measured on the GPU: bit-exact (162 tests) and SLOWER than the compiler's fp32 expansion - C2 -7 %, C5 -3 %, C4 -4 % (profiles/r04_ab_div64_*.txt):
+                            // the fp64 chain is shorter in instructions and longer in cycles.  Kept as a tested alternative.
+#endif
+#ifdef RT_MODE_FAST
+#undef RT_DIV64
+#define RT_DIV64 0
+#endif
+#define RT_DIV64_FN __device__ __forceinline__
+#include "rt_div64.h"
+// (the plain operators: one real function each - they run for operands outside the fast path's range, never on the render path's unit vectors and radii -
+// so that the compiler's division / square-root expansions exist once per kernel instead of once per call site)
+__device__ __attribute__((noinline)) f3 rt_div3_plain(f3 a, float t) { return { a.x / t, a.y / t, a.z / t }; }
+__device__ __forceinline__ f3 operator/(f3 a, float t) {                                               // vec3.h:79
+#if RT_DIV64
+    const float at = fabsf(t);
+    if (at >= 0x1p-60f && at <= 0x1p60f) {
+        float q[3];
+        if (rt_div3_64(a.x, a.y, a.z, rt_recip64((double)t, (double)__builtin_amdgcn_rcpf(t)), q)) return { q[0], q[1], q[2] };
+    }
+    return rt_div3_plain(a, t);
+#else
+    return { a.x / t, a.y / t, a.z / t };
+#endif
+}
 __device__ __forceinline__ f3 operator-(f3 a) { return { -a.x, -a.y, -a.z }; }                         // vec3.h:23
 __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }         // vec3.h:87
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {                                                      // vec3.h:91
@@ -53,7 +80,21 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {                               
 }
 __device__ __forceinline__ float sqlen(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }             // vec3.h:36
 __device__ __forceinline__ float len(f3 a) { return rt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }   // vec3.h:35
-__device__ __forceinline__ f3 unit(f3 a) { return a / len(a); }                                        // vec3.h:194
+__device__ __forceinline__ f3 unit(f3 a) {                                                             // vec3.h:194: a / sqrt(squared_length)
+#if RT_DIV64
+    const float s = a.x * a.x + a.y * a.y + a.z * a.z;                                                 // vec3.h:35-36, the reference's roundings
+    if (s >= 0x1p-100f && s <= 0x1p100f) {
+        double h;
+        const float l = rt_sqrt64(s, (double)__builtin_amdgcn_rsqf(s), &h);                            // == __builtin_sqrtf(s)
+        float q[3];
+        if (rt_div3_64(a.x, a.y, a.z, rt_recip64((double)l, h + h), q)) return { q[0], q[1], q[2] };   // (l differs from sqrt(s) by <= 2^-25: a fine seed)
+        return rt_div3_plain(a, l);
+    }
+    return rt_div3_plain(a, rt_sqrt(s));
+#else
+    return a / len(a);
+#endif
+}
 __device__ __forceinline__ float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }                    // vec3.h:113
 
 // ---- rnd.h ------------------------------------------------------------------------------------

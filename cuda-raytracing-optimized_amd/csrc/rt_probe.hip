@@ -135,7 +135,7 @@ __global__ void k_scatter(const float* t, const float* hp, const float* normal, 
 __global__ void k_math(const float* a, const float* b, int n, float* quot, float* root, float* p5, float* unit3) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    quot[k] = a[k] / b[k];
+    quot[k] = (F3(a[k], 0.0f, 1.0f) / b[k]).x;                     // vec3 / float as the path computes it (rt_div64.h)
     root[k] = rt_sqrt(fabsf(a[k]));
     p5[k] = pow5(a[k]);
     stv(unit3, k, unit(F3(a[k], b[k], a[k] - b[k])));

@@ -872,3 +872,83 @@ void orc_libm_powf5(const float* x, int n, float* out) {
 void orc_schlick_array(const float* cosine, const float* ref_idx, int n, float* out) {
     for (int k = 0; k < n; k++) out[k] = orc_schlick(cosine[k], ref_idx[k]);
 }
+
+/* ---- the device's vec3 / float and unit_vector through fp64, checked against IEEE division and sqrtf ----------------------------------------
+ * cuda-raytracing-optimized_amd/csrc/rt_div64.h computes (ax, ay, az) / t and sqrt(s) through an fp64 reciprocal / iteration; the same text is compiled
+ * here and compared with the plain fp32 operators, with the hardware seeds (v_rcp_f32, v_rsq_f32: 1 ulp) replaced by fp32 values pushed off by up to
+ * +-2 ulp - the result must not depend on them.  Test infrastructure (tests/test_oracle_golden.py). */
+#define RT_DIV64_FN static inline
+#include "../cuda-raytracing-optimized_amd/csrc/rt_div64.h"
+
+typedef struct { uint64_t seed; long n; int mode; long bad, done; float bad_x, bad_y; } div64_job;
+static inline uint64_t d64_next(uint64_t* s) { *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17; return *s; }
+static inline float d64_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float d64_nudge(float f, int k) { uint32_t u; memcpy(&u, &f, 4); u += (uint32_t)k; memcpy(&f, &u, 4); return f; }
+static void* div64_worker(void* arg) {
+    div64_job* j = (div64_job*)arg;
+    uint64_t st = j->seed * 0x9E3779B97F4A7C15ull + 1;
+    for (long i = 0; i < j->n; i++) {
+        const uint64_t a = d64_next(&st), b = d64_next(&st);
+        const int nud = (int)(b >> 61) - 3 + ((b >> 60) & 1);                /* -3 .. +4 -> clamp to +-2 below */
+        const int k = nud < -2 ? -2 : (nud > 2 ? 2 : nud);
+        if (j->mode == 0 || j->mode == 1) {                                 /* division: random operands (0) or quotients beside a rounding boundary (1) */
+            float y = d64_bits(0x3F800000u - (40u << 23) + (uint32_t)((a >> 8) % (80u << 23)));       /* 2^-40 .. 2^40 */
+            float x;
+            if (j->mode == 0) x = d64_bits((uint32_t)(b & 0x7FFFFFFFu) % 0x7F000000u) * ((a & 1) ? -1.0f : 1.0f);
+            else {                                                          /* x = RN(y * (2M + 1) 2^-25 * 2^e): x / y lies within an ulp of x of a boundary */
+                const double m = (double)((((b >> 8) & 0xFFFFFFu) | 0x800000u) * 2u + 1u) * 0x1p-25;
+                x = (float)((double)y * m * (double)d64_bits(0x3F800000u - (20u << 23) + (uint32_t)((b >> 40) % 40u) * (1u << 23)));
+            }
+            if (a & 2) y = -y;
+            const float ay = fabsf(y);
+            if (!(ay >= 0x1p-60f && ay <= 0x1p60f)) continue;
+            const float x2 = d64_bits((uint32_t)(a >> 32)), x3 = x * 0.333f;
+            float q[3];
+            const double r = rt_recip64((double)y, (double)d64_nudge(1.0f / y, k));
+            if (!rt_div3_64(x, x2, x3, r, q)) continue;                     /* left to the plain operators */
+            const float e0 = x / y, e1 = x2 / y, e2 = x3 / y;
+            j->done++;
+            if (memcmp(&q[0], &e0, 4) || (memcmp(&q[1], &e1, 4) && !(q[1] != q[1] && e1 != e1)) || memcmp(&q[2], &e2, 4)) { if (!j->bad) { j->bad_x = x; j->bad_y = y; } j->bad++; }
+        } else {                                                            /* square root: random (2) or beside a boundary (3), then the unit-vector division by it */
+            float s;
+            if (j->mode == 2) s = d64_bits(0x3F800000u - (90u << 23) + (uint32_t)((a >> 8) % (180u << 23)));
+            else {
+                const double m = (double)((((b >> 8) & 0xFFFFFFu) | 0x800000u) * 2u + 1u) * 0x1p-25 * ((a & 4) ? 1.0 : 1.4142135623730951);
+                s = (float)(m * m * (double)d64_bits(0x3F800000u - (20u << 23) + (uint32_t)((b >> 40) % 40u) * (1u << 23)));
+            }
+            if (!(s >= 0x1p-100f && s <= 0x1p100f)) continue;
+            double h;
+            const float l = rt_sqrt64(s, (double)d64_nudge(1.0f / sqrtf(s), k), &h), e = sqrtf(s);
+            int bad = memcmp(&l, &e, 4) != 0;
+            float q[3];
+            j->done++;
+            const float x = d64_bits((uint32_t)(b & 0x7FFFFFFFu) % 0x7F000000u) * 1e-19f;
+            if (!bad && rt_div3_64(x, l, -l, rt_recip64((double)l, h + h), q)) {
+                const float e0 = x / l, e1 = l / l, e2 = -l / l;
+                bad = memcmp(&q[0], &e0, 4) || memcmp(&q[1], &e1, 4) || memcmp(&q[2], &e2, 4);
+            }
+            if (bad) { if (!j->bad) { j->bad_x = s; j->bad_y = l; } j->bad++; }
+        }
+    }
+    return 0;
+}
+/* n cases of `mode` (0 / 1 division: random / beside a rounding boundary; 2 / 3 square root likewise) over `threads` host threads: the number of cases in
+ * which rt_div64.h's result differs from the plain fp32 operator in any bit; bad2 = the operands of one such case. */
+long orc_div64_twin_mismatches(int mode, long n, uint64_t seed, int threads, float* bad2, long* compared) {
+    pthread_t th[64];
+    div64_job job[64];
+    long bad = 0;
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    for (int k = 0; k < threads; k++) {
+        job[k].seed = seed * 64 + (uint64_t)k; job[k].n = n / threads; job[k].mode = mode; job[k].bad = 0; job[k].done = 0; job[k].bad_x = job[k].bad_y = 0.0f;
+        pthread_create(&th[k], 0, div64_worker, &job[k]);
+    }
+    for (int k = 0; k < threads; k++) {
+        pthread_join(th[k], 0);
+        if (job[k].bad && bad == 0 && bad2) { bad2[0] = job[k].bad_x; bad2[1] = job[k].bad_y; }
+        bad += job[k].bad;
+        if (compared) *compared += job[k].done;
+    }
+    return bad;
+}

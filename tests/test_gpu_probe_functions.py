@@ -46,6 +46,36 @@ def test_basic_math_is_ieee(probe, lib):
     assert np.array_equal(_bits(p5), _bits(lp))
 
 
+def test_division_and_unit_vector_through_fp64_are_ieee(probe):
+    """vec3 / float and unit_vector on the device go through an fp64 reciprocal / square-root iteration (csrc/rt_div64.h; the host twin of the same text is held to
+    IEEE on 2^29 cases in test_div64_twin_is_ieee).  Here the DEVICE's bits - v_rcp_f32 / v_rsq_f32 seeds included - on 2^20 operand pairs: random ones, quotients beside
+    rounding boundaries, unit vectors and nearly-unit vectors (the render path's case), tiny and huge lengths (the plain-operator fall-backs)."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    b = (rng.uniform(0.001, 1000, n) * rng.choice([-1, 1], n)).astype(np.float32)
+    m = ((rng.integers(1 << 23, 1 << 24, n) * 2 + 1).astype(np.float64) * 2.0 ** -25)
+    a = np.where(np.arange(n) % 2 == 0, rng.uniform(-1000, 1000, n), b.astype(np.float64) * m * 2.0 ** rng.integers(-8, 8, n)).astype(np.float32)
+    a[:8] = (0.0, -0.0, 1e-30, -1e-30, 1e30, 3.0, 1.0, 1e-38); b[:8] = (2.0, 3.0, 1e10, 1e12, 1e-20, 3.0, 1e-25, 7.0)
+    q, r, _, u3 = probe.math(a, b)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(_bits(q), _bits(a / b))
+        assert np.array_equal(_bits(r), _bits(np.sqrt(np.abs(a))))
+        v = np.stack([a, b, a - b], 1)
+        ln = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
+        assert np.array_equal(_bits(u3), _bits(v / ln[:, None]))
+    # nearly-unit vectors (what hit() renormalises) and tiny / huge ones
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    scale = np.where(np.arange(n) % 16 == 0, 10.0 ** rng.uniform(-30, 30, n), 1.0)
+    d = (d * scale[:, None]).astype(np.float32)
+    _, _, _, u3 = probe.math(d[:, 0], d[:, 1])               # unit(F3(a, b, a - b)): two free components
+    with np.errstate(all="ignore"):
+        v = np.stack([d[:, 0], d[:, 1], d[:, 0] - d[:, 1]], 1)
+        ln = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
+        want = v / ln[:, None]
+    ok = np.isfinite(want).all(axis=1)
+    assert ok.mean() > 0.9 and np.array_equal(_bits(u3[ok]), _bits(want[ok]))
+
+
 def test_powf5_and_schlick_are_the_cpu_libm(probe, lib):
     """material.h:9-13: schlick calls pow(1 - cosine, 5.0f) - powf, glibc's on the CPU side.  The device runs that algorithm restated
     (csrc/rt_glibc_powf.h; on the host the same text equals libm on every float: test_glibc_powf5_twin_is_libm).  Here the DEVICE's bits: powf(x, 5) on

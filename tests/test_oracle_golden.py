@@ -242,3 +242,21 @@ def test_host_io_against_fixtures_minted_from_the_reference_code(rt, tmp_path):
     assert rc == 0 and back.tobytes() == fb.tobytes()
     for (nx, ny), want in zip(g["cam_sizes"], g["cams"]):
         assert bytes(rt.staircase_camera(int(nx), int(ny))) == want.tobytes(), (nx, ny)
+
+
+def test_div64_twin_is_ieee(O):
+    """cuda-raytracing-optimized_amd/csrc/rt_div64.h - vec3 / float (vec3.h:79) and the square root of unit_vector (vec3.h:35,194) as the DEVICE computes them, through an
+    fp64 reciprocal / iteration - compiled for the host (oracle/rt_oracle.c includes the same text) equals the plain IEEE fp32 operators in every bit: 2^27 random
+    operand pairs and 2^27 quotients constructed to lie beside a rounding boundary of the float grid (x = RN(y (2M + 1) 2^-25 2^e)), the same for square roots
+    (s = RN(m^2) for boundaries m), with the hardware seeds replaced by values up to 2 ulp off (the result must not depend on them)."""
+    import ctypes as C
+    import os
+    lib = O.load_oracle()
+    f = lib.orc_div64_twin_mismatches
+    f.restype = C.c_long
+    f.argtypes = [C.c_int, C.c_long, C.c_uint64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_long)]
+    threads = min(8, os.cpu_count() or 1)
+    for mode in range(4):
+        bad, compared = (C.c_float * 2)(), C.c_long(0)
+        assert f(mode, 1 << 27, 11 + mode, threads, bad, C.byref(compared)) == 0, (mode, bad[0], bad[1])
+        assert compared.value > 0.7 * (1 << 27), (mode, compared.value)
