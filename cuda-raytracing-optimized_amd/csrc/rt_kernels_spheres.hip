@@ -1780,7 +1780,15 @@ static hipError_t launch_queue_kernel_scene(const RtSphereParams& q, unsigned bl
     // (time lines of the PRODUCTION kernel of the benchmark scene - RT_WAVE_DEBUG with RT_WAVE_DEBUG_LIGHT=1, no counters: the lean kind 3 with the stamps)
     if (counting && q.counters == nullptr && SCENE == 0 && !CHUNKED && PHASE != 0 && g_lean_dbg == 3) return go(k_render_spheres_queue<PHASE, CLS, false, true, 0, 3>);
     if (counting) return go(k_render_spheres_queue<PHASE, CLS, CHUNKED, true, SCENE>);
-    if (SCENE == 0 && !CHUNKED) {                                    // (the sample chunks of the counter stream take the general kernel)
+    if (SCENE == 0 && CHUNKED) {                                     // the sample chunks of the counter stream: the kinds of the benchmark's shape
+        switch (g_lean) {
+        case 1:  return go(k_render_spheres_queue<PHASE, CLS, true, false, 0, 1>);
+        case 3:  return go(k_render_spheres_queue<PHASE, CLS, true, false, 0, 3>);
+        case 7:  return go(k_render_spheres_queue<PHASE, CLS, true, false, 0, 7>);
+        default: break;
+        }
+    }
+    if (SCENE == 0 && !CHUNKED) {
         switch (g_lean) {
         case 1:  return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 1>);
         case 3:  return go(k_render_spheres_queue<PHASE, CLS, false, false, 0, 3>);
@@ -1854,7 +1862,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
     g_lean = 0;
     int lean_wgs = 1;
     g_lean_dbg = 0;
-    if (kind == 0 && !p.global_scene && p.basic_materials && basic_env && p.chunks == 1) {
+    if (kind == 0 && !p.global_scene && p.basic_materials && basic_env) {
         const int n_small_groups = p.n_groups - p.n_big_groups;
         g_lean = 1;
         if (cull && p.cell_on != 0 && n_small_groups >= 1 && n_small_groups <= 128 && onepass_env) {
@@ -1864,6 +1872,7 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
             if (p.box_shared_axis != 2) g_lean |= 8;                             // no shared vertical extent: the 3-axis prefilter
         }
     }
+    if (p.chunks > 1 && g_lean != 1 && g_lean != 3) g_lean &= 1;             // (sample chunks: kinds 1, 3 and 7 are built)
     static const bool dbg_light_env = getenv("RT_WAVE_DEBUG_LIGHT") && getenv("RT_WAVE_DEBUG_LIGHT")[0] == '1';
     // (only a frame that takes the two cost-ordered dispatches: its two kernels are the ones instantiated with the stamps)
     const bool two_phase_frame = ((variant >> 24) & 3) == 0 && p.order && p.px_state && p.px_rays && p.chunks == 1 && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.ns >= 8 &&
