@@ -22,6 +22,7 @@
 
 #include <float.h>
 #include <cstdlib>
+#include <cstring>
 
 using namespace rtd;
 
@@ -317,10 +318,19 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
 // LEAN (the launcher's promise: every material is RT_DIFFUSE / RT_METAL / RT_GLASS without a texture - what scene_materials.h:13-20 at HEAD can produce -, no
 // floor plane, pair rounds available): PROCESS without the preset tables, textures and the plane, no (u, v) carried through the traversal - fewer registers,
 // so more waves per SIMD (RT_MESH_LEAN_WAVES) to hide the dependent node loads behind.
+#ifndef RT_MESH_HEAVY_CLS
+#define RT_MESH_HEAVY_CLS 5         // PHASE 2: cost classes counted as expensive (>= 1.6 x the mean pixel) and spread over the first fills (0 = off) ...
+#define RT_MESH_SPREAD_ROUNDS 2     // ... of this many times the lanes in flight.  C4, A/B in one call (profiles/r04_sweep_mesh_spread*.txt): lists as they lie 907, 5 classes over
+                                    // 1 / 2 / 3 / 5 fills 972 / 937-987 / 954 / 938, 4 classes 969 / 967, 6 classes 903 / 945, 7 classes 905-919 Msamples/s
+#endif
 #ifndef RT_MESH_LEAN_WAVES
 #define RT_MESH_LEAN_WAVES 4
 #endif
-template <int TRAV, bool DBG, bool STATS, bool LEAN = false>
+// PHASE (the cost-ordered frame, rt_params.h): 0 = whole pixels in one dispatch (scattered order); 1 = samples [0, s_split) of every pixel, then park the pixel;
+// 2 = resume the parked pixels in the order of P.order (longest first).  A frame ends one pixel-time after its queue runs empty, and a pixel of C4 is 1/8 of a
+// lane's frame: in scattered order the 1920x1080x256 frame ran at 782 Msamples/s where the same samples as a 3840x2160x64 frame ran at 1106
+// (profiles/r04_mesh_tail_probe.txt) - the expensive pixels were still running when everything else was done.
+template <int TRAV, bool DBG, bool STATS, bool LEAN = false, int PHASE = 0>
 __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV == 0 ? 4 : 5)) k_render_mesh_queue(const RtMeshParams P, uint32_t stride, int min_traversing, int leaf_thr) {
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
@@ -352,6 +362,24 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     const f3 lightC = ld3(P.light.center);
     const float lightR = P.light.radius;
     float* fbf = reinterpret_cast<float*>(P.fb);
+    // PHASE 2 work order.  P.order holds the pixels by descending cost class.  Taken as it lies, the first fill gives every wave 64 pixels of the top class - and a
+    // pixel advances one node step per step of its wave, whose time grows with the lanes that are traversing (the loads, not their latency, bound a step): a wave
+    // full of long traversals makes each of them ~1.5x longer, and the frame ends with them.  So the expensive lists (the first `heavy_cls` classes: nH pixels)
+    // are SPREAD evenly over the first S queue positions, S = spread_rounds x (lanes in flight): position p takes an expensive pixel iff floor((p + 1) nH / S) >
+    // floor(p nH / S), else the next of the rest (also by descending cost).  (leaf_thr >> 8: heavy_cls | spread_rounds << 4, from the launcher.)
+    __shared__ uint32_t s_m[4];         // [0] nH  [1] S  (PHASE 2)
+    if (PHASE == 2 && threadIdx.x == 0) {
+        const int heavy_cls = (leaf_thr >> 8) & 0xF, rounds = (leaf_thr >> 12) & 0xF;
+        uint32_t nH = 0;
+        for (int c = 0; c < heavy_cls; c++) nH += P.queue[4 + c];
+        const uint32_t N = (uint32_t)P.part.local_rows * (uint32_t)P.nx;
+        uint32_t S = (uint32_t)rounds * gridDim.x * blockDim.x;
+        if (S > N) S = N;
+        if (heavy_cls == 0 || rounds == 0 || nH == 0u || nH > S || S - nH > N - nH) { nH = 0u; S = 0u; }      // (off: the lists as they lie)
+        s_m[0] = nH; s_m[1] = S;
+    }
+    if (PHASE == 2) __syncthreads();
+    leaf_thr &= 0xFF;
 
     // path state (path, helper_structs.h:48-71)
     uint32_t rng = 1;
@@ -367,6 +395,9 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     bool have_pixel = false, exhausted = false;
     TravStats st = { 0, 0 };
     uint32_t nrays = 0, nshadow = 0;
+    uint32_t pix_jobs = 0;              // PHASE 1: node visits of this pixel so far: its measured cost
+    const int s_end = PHASE == 1 ? P.s_split : P.ns;
+    const uint32_t n_items = PHASE == 2 ? (uint32_t)P.part.local_rows * (uint32_t)P.nx : total;      // the lists hold the valid pixels only
     // diagnostics (P.dbg): cycles and active lanes per phase, per wave; summed over the waves at the end
     unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
@@ -533,8 +564,13 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
             if (path_done) {
                 col = col + pcolor;                                  // kernels.cu:558
                 s++;
-                if (s < P.ns) {
+                if (s < s_end) {
                     need_sample = true;
+                } else if (PHASE == 1) {                             // first samples done: park the pixel (colour sum, stream position, cost)
+                    const size_t px = (size_t)lr * P.nx + pi;
+                    P.px_state[px] = make_float4(col.x, col.y, col.z, __uint_as_float(rng));
+                    P.px_rays[px] = (pix_jobs + 12u) / 24u;         // in the ordering pass's unit: ~150 node visits per sample are ~6 "rays" per sample (class thresholds of cost_class)
+                    have_pixel = false;
                 } else {
                     const f3 out = col / (float)P.ns;                // kernels.cu:568
                     // one 12-byte store (global_store_dwordx3): a lane finishes its pixel on its own, three dword stores are three partial-sector writes
@@ -553,10 +589,31 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
             uint32_t base = 0;
             if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue, cnt);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= total) { exhausted = true; break; }
+            if (base >= n_items) { exhausted = true; break; }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (base + cnt >= total) exhausted = true;
-            if (!have_pixel && base + rank < total) {
+            if (base + cnt >= n_items) exhausted = true;
+            if (!have_pixel && base + rank < n_items) {
+                if (PHASE == 2) {                                    // resume: the pixel's stream continues where the first dispatch left it
+                    uint32_t pos = (stride == 0xFFFFFFFFu) ? n_items - 1u - (base + rank) : base + rank;      // (stride ~0: experiment, cheapest first)
+                    const uint32_t nH = s_m[0], S = s_m[1];
+                    if (nH != 0u && stride != 0xFFFFFFFFu) {
+                        if (pos < S) {
+                            const uint32_t before = (uint32_t)(((unsigned long long)pos * nH) / S);
+                            const uint32_t after = (uint32_t)(((unsigned long long)(pos + 1u) * nH) / S);
+                            pos = after > before ? before : nH + (pos - before);
+                        }                                            // (pos >= S: every expensive pixel is out: the rest list at nH + (pos - nH) = pos)
+                    }
+                    const uint32_t packed = P.order[pos];
+                    const float4 st4 = P.ord_state[pos];
+                    pi = (int)(packed & 0xFFFFu); lr = (int)(packed >> 16);
+                    pj = global_row(P.part, lr);
+                    pixelId = (uint32_t)(pj * P.nx + pi);
+                    rng = __float_as_uint(st4.w);
+                    col = F3(st4.x, st4.y, st4.z);
+                    s = P.s_split;
+                    have_pixel = true;
+                    need_sample = true;
+                } else {
                 const uint32_t p = (uint32_t)(((unsigned long long)(base + rank) * stride) % total);
                 const uint32_t tile = p >> 6, within = p & 63u;
                 const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
@@ -568,8 +625,10 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                     rng = pixel_seed(pixelId);
                     col = F3(0, 0, 0);
                     s = 0;
+                    pix_jobs = 0;
                     have_pixel = true;
                     need_sample = true;
+                }
                 }
             }
         }
@@ -614,6 +673,7 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                     if (dbg) { g_act[2] += (unsigned long long)n_node; g_it[2]++; }
                     const bool at_node = J.idx != 0 && (uint32_t)J.idx < P.first_leaf;
                     if (at_node) {
+                        if (PHASE == 1) pix_jobs++;                  // the pixel's measured cost: node visits (rays differ little between pixels, their traversals a lot)
                         const int idx2 = J.idx << 1;
                         // child pair of node idx from its axis-grouped record (rt_params.h): per axis (near_L, near_R, far_L, far_R)
                         const char* rec = reinterpret_cast<const char*>(P.bvh_axis);
@@ -898,6 +958,36 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
     const dim3 grid((unsigned)blocks), block(kThreads);
     const size_t lds = (!classic && p.leaf_ofs && p.first_leaf <= kLeafCntLds) ? (size_t)((p.first_leaf + 15u) & ~15u) : 0;      // the leaf-count table
     // the counting instantiation (STATS: the reference's ray statistics as device atomics) runs only when counters are asked for
+    // The cost-ordered frame in two dispatches (template parameter PHASE): reference RNG stream, no diagnostics, enough samples for the first few to be a small part.
+    // RT_MESH_TWO=0: the single scattered dispatch (A/B); RT_MESH_SPLIT=<n>: samples of the first dispatch.
+    static const bool two_env = !(getenv("RT_MESH_TWO") && getenv("RT_MESH_TWO")[0] == '0');
+    static const int split_env = getenv("RT_MESH_SPLIT") ? atoi(getenv("RT_MESH_SPLIT")) : 2;      // (1: 903, 2: 911, 4: 893, 8: 866 Msamples/s on C4, profiles/r04_ab_mesh_two_b.txt)
+    const int split = split_env < 1 ? 1 : split_env;
+    if (two_env && !classic && !p.dbg && !p.counters && p.rng_mode == RT_RNG_REFERENCE_STREAM && p.px_state && p.px_rays && p.order && p.ord_state && p.ord_rays &&
+        p.ns >= 4 * split && p.nx <= 65535 && p.part.local_rows <= 65535) {
+        RtMeshParams q = p;
+        q.s_split = split;
+        if (lean) hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, true, 1>), grid, block, lds, stream, q, stride, min_traversing, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, false, 1>), grid, block, lds, stream, q, stride, min_traversing, leaf_thr);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(p.queue, 0, 256, stream);
+        if (e != hipSuccess) return e;
+        RtSphereParams o;                                            // what the ordering pass reads (rt_params.h: rt_order_pixels_by_cost)
+        memset(&o, 0, sizeof o);
+        o.nx = p.nx; o.ny = p.ny; o.part = p.part; o.s_split = split; o.chain_top_thr = 384;
+        o.px_rays = p.px_rays; o.px_state = p.px_state; o.order = p.order; o.ord_state = p.ord_state; o.ord_rays = p.ord_rays; o.queue = p.queue;
+        e = rt_order_pixels_by_cost(o, stream);
+        if (e != hipSuccess) return e;
+        static const bool rev_env = getenv("RT_MESH_REV") && getenv("RT_MESH_REV")[0] == '1';       // experiment: cheapest pixels first
+        static const int heavy_env = getenv("RT_MESH_HEAVY") ? atoi(getenv("RT_MESH_HEAVY")) : RT_MESH_HEAVY_CLS;       // expensive classes spread over the first fills
+        static const int rounds_env = getenv("RT_MESH_ROUNDS") ? atoi(getenv("RT_MESH_ROUNDS")) : RT_MESH_SPREAD_ROUNDS;
+        const uint32_t stride2 = rev_env ? 0xFFFFFFFFu : stride;
+        const int lt2 = leaf_thr | ((heavy_env & 0xF) << 8) | ((rounds_env & 0xF) << 12);
+        if (lean) hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, true, 2>), grid, block, lds, stream, q, stride2, min_traversing, lt2);
+        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, false, 2>), grid, block, lds, stream, q, stride2, min_traversing, lt2);
+        return hipGetLastError();
+    }
     if (classic) {
         if (p.dbg) hipLaunchKernelGGL((k_render_mesh_queue<1, true, false>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);
         else if (p.counters) hipLaunchKernelGGL((k_render_mesh_queue<1, false, true>), grid, block, lds, stream, p, stride, min_traversing, leaf_thr);

@@ -1736,6 +1736,11 @@ static size_t lds_bytes(int n_padded, int n, bool with_fb, int scene = 0, int wa
 }
 
 #if defined(RT_MODE_PARITY)
+hipError_t rt_order_pixels_by_cost(const RtSphereParams& q, hipStream_t stream) {
+    hipLaunchKernelGGL(k_order_by_cost<0>, dim3(kOrderBlocks), dim3(kThreads), 0, stream, q);
+    hipLaunchKernelGGL(k_order_by_cost<1>, dim3(kOrderBlocks), dim3(kThreads), 0, stream, q);
+    return hipGetLastError();
+}
 size_t rt_sphere_kernel_lds_bytes(int n_padded, int n) {                       // of the smallest LDS-resident form: beyond it the scene is read from global memory
     return lds_bytes(n_padded, n, false, 2, 8) + kStaticLds;
 }

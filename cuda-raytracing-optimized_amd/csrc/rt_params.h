@@ -138,10 +138,22 @@ struct RtMeshParams {
     RtCounters* counters;
     uint32_t* queue;
     unsigned long long* dbg;    // diagnostics (RT_WAVE_DEBUG): 16 phase counters summed over all waves, or nullptr
+    // cost-ordered frame in two dispatches (reference RNG stream; rt_launch_mesh_*): the first renders samples [0, s_split) of every pixel and parks (colour sum,
+    // stream position) and the rays it took; rt_order_pixels_by_cost sorts the pixels by that cost into queue order; the second resumes them longest first
+    int32_t s_split;
+    float4* px_state;           // local_rows * nx
+    uint32_t* px_rays;          // local_rows * nx
+    uint32_t* order;            // queue position -> (local row << 16 | column)
+    float4* ord_state;          // the parked state in queue order
+    uint32_t* ord_rays;
 };
 
 // LDS the sphere kernel needs for a scene of n spheres (n_padded slots).
 size_t rt_sphere_kernel_lds_bytes(int n_padded, int n);
+// The ordering pass of the two-dispatch frames (rt_kernels_spheres.hip, k_order_by_cost; also used by the mesh launcher): reads px_rays / px_state / s_split /
+// chain_top_thr / nx / part.local_rows of `q`, writes order / ord_state / ord_rays (all valid pixels, descending cost class, scattered inside a class) and the
+// list lengths into q.queue[4..]; q.queue must have been zeroed on `stream` before.
+hipError_t rt_order_pixels_by_cost(const RtSphereParams& q, hipStream_t stream);
 
 // Each returns the hipError_t of the launch.  `variant` selects a kernel variant (0 = default).
 // Sphere launchers: p.self must point to a device copy of `p` that is complete on `stream` before the launch (the renderer owns it).

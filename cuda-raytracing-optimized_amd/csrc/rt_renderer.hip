@@ -233,7 +233,7 @@ void setup_devices() {
         if (d.fb_rows > 0) {        // work-order lists of the persistent kernels: 3 x (pixels padded to 8x8 tiles)
             const size_t padded = (size_t)((c.nx + 7) / 8) * ((d.fb_rows + 7) / 8) * 64;
             HIP_CHECK(hipMalloc((void**)&d.d_order, 3 * padded * sizeof(uint32_t)));
-            if (c.is_spheres) {
+            {                                                       // the two-dispatch frames of both kernels: parked state + its copy in queue order
                 HIP_CHECK(hipMalloc((void**)&d.d_px_state, d.fb_rows * c.nx * sizeof(float4)));
                 HIP_CHECK(hipMalloc((void**)&d.d_px_rays, d.fb_rows * c.nx * sizeof(uint32_t)));
                 HIP_CHECK(hipMalloc((void**)&d.d_ord_state, padded * sizeof(float4)));
@@ -758,6 +758,7 @@ void runRenderer(int ns, int tx, int ty) {
             if (c.opt.floor && (c.opt.variant & 0xFF) == 1) rt_fail("runRenderer: the floor plane is not built into the tile-per-wave A/B kernel (variant 1)");
             p.counters = c.opt.counters ? d.d_counters : nullptr;
             p.queue = d.d_queue;
+            p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays; p.order = d.d_order; p.ord_state = d.d_ord_state; p.ord_rays = d.d_ord_rays;
             if (getenv("RT_WAVE_DEBUG")) {                           // diagnostics: phase cycle / lane counters -> file
                 const size_t dbg_bytes = (size_t)65536 * 8 * sizeof(unsigned long long);
                 if (!d.d_wave_dbg) HIP_CHECK(hipMalloc((void**)&d.d_wave_dbg, dbg_bytes));

@@ -292,3 +292,38 @@ def test_floor_and_stats_with_nee_bit_exact(rt, O, stair):
     for k in range(18):
         assert int(st.ref_stats[k]) == int(cnt.ref_stats[k]), rt.RT_STAT_NAMES[k]
     assert st.ref_stats[rt.RT_STAT_SHADOWS] == st.shadow_rays > 0
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_two_dispatch_cost_ordered_mesh_frame_bit_exact(rt, O, stair, textured):
+    """From 16 spp the mesh frame is rendered in two dispatches (rt_kernels_mesh.hip, PHASE): 4 samples of every pixel measure its cost and park it (colour sum,
+    stream position), the ordering pass of the sphere kernel sorts the pixels longest first, the second dispatch resumes every stream where it stopped.  No sample
+    is traced twice or differently: the frame equals the oracle's bit for bit - the lean instantiation (untextured basic materials) and the general one (a
+    textured scene), NEE + RR on - and equals the single dispatch (8 spp prefix of the same streams is covered by the other tests); three stripe members too."""
+    hm, mats = stair
+    tex = []
+    if textured:
+        mats = mats.copy()
+        rng = np.random.default_rng(3)
+        tex = [rng.uniform(0, 1, (16, 24, 3)).astype(np.float32)]
+        mats["texId"][17] = 0; mats["texId"][19] = 0
+    nx, ny, ns = 56, 72, 20
+    cam = rt.staircase_camera(nx, ny)
+    ref, _ = O.render(O.mesh_scene(hm, mats, tex), cam, O.default_options(False), nx, ny, ns, 24)
+    ks, keep = rt.make_kernel_scene(hm, mats, tex)
+    fb = rt.initRenderer(ks, cam, nx, ny, 24, keepalive=keep)
+    rt.runRenderer(ns, 8, 8)
+    got = np.array(fb, copy=True)
+    assert np.array_equal(_bits(got), _bits(ref)), np.count_nonzero(_bits(got) != _bits(ref))
+    rt.runRenderer(ns, 8, 8)                                         # a second frame into the same buffers (queue, lists, parked state are per frame)
+    assert np.array_equal(_bits(np.array(fb)), _bits(ref))
+    o = rt.getDefaultRenderOptions(False)
+    merged = np.zeros_like(got)
+    for r in range(3):
+        rt.setRenderOptions(o, part_rank=r, part_world=3, stripe_rows=8)
+        rt.runRenderer(ns, 8, 8)
+        part = np.array(fb, copy=True)
+        for k in range(r, (ny + 7) // 8, 3):
+            merged[k * 8:(k + 1) * 8] = part[k * 8:(k + 1) * 8]
+    rt.cleanupRenderer()
+    assert np.array_equal(_bits(merged), _bits(ref))
