@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/make_traffic_json.py <tag> — condenses gpurun_out/prof_<tag>_{C2,C4}/ (tools/measure_traffic.sh) into
 gpurun_out/<tag>_{C2,C4}_summary.txt and gpurun_out/traffic.json; copy both to profiles/ to have them judged.
-Per-frame figures = the dispatches of the LAST full frame of each pass (the render kernel runs twice per frame on C2: the
+Per-frame figures = the dispatches of the LAST full frame of each pass (the render kernel runs twice per frame: the
 first samples, then the cost-ordered rest)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -20,7 +20,7 @@ def rows(d, pattern):
                 yield r
 
 
-for W, per_frame in (("C2", 2), ("C4", 1), ("C3", 2), ("C5", 2)):
+for W, per_frame in (("C2", 2), ("C4", 2), ("C3", 2), ("C5", 2)):      # (C4: two dispatches per frame since round 4)
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{W}")
     if not os.path.isdir(d):
         continue
