@@ -23,6 +23,8 @@
 #include <float.h>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
+#include <cstdio>
 
 using namespace rtd;
 
@@ -323,6 +325,18 @@ __device__ __forceinline__ void job_start(const RtMeshParams& P, Job& J, f3 org,
 #define RT_MESH_SPREAD_ROUNDS 2     // ... of this many times the lanes in flight.  C4, A/B in one call (profiles/r04_sweep_mesh_spread*.txt): lists as they lie 907, 5 classes over
                                     // 1 / 2 / 3 / 5 fills 972 / 937-987 / 954 / 938, 4 classes 969 / 967, 6 classes 903 / 945, 7 classes 905-919 Msamples/s
 #endif
+#ifndef RT_MESH_CHAIN_THR
+#define RT_MESH_CHAIN_THR 448       // PHASE 2: list 0 = pixels from 16 x this many cost units per sample (the mean pixel of C4 has ~100): the chains, see "Chain waves"
+#endif
+#ifndef RT_MESH_CHAIN_LANES
+#define RT_MESH_CHAIN_LANES 6       // pixels of list 0 per chain wave (0 = no chain waves)
+#endif
+#ifndef RT_MESH_TAIL_DIAG
+#define RT_MESH_TAIL_DIAG 0
+#endif
+#if RT_MESH_TAIL_DIAG
+__device__ uint32_t* g_diag_items;      // per pixel: (start, end) of its second-dispatch item, microseconds
+#endif
 #ifndef RT_MESH_LEAN_WAVES
 #define RT_MESH_LEAN_WAVES 4
 #endif
@@ -336,6 +350,9 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
     const float eps = P.t_min;
+#if RT_MESH_TAIL_DIAG
+    const unsigned long long t_start_diag = __builtin_amdgcn_s_memrealtime();
+#endif
     // leaf phase of TRAV 0: per-wave LDS scratch and this lane's fixed role in a pair round (ray j / nppl, triangle j % nppl)
     __shared__ uint32_t s_owner[kThreads];
     __shared__ unsigned long long s_best[kThreads];
@@ -372,13 +389,25 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
         const int heavy_cls = (leaf_thr >> 8) & 0xF, rounds = (leaf_thr >> 12) & 0xF;
         uint32_t nH = 0;
         for (int c = 0; c < heavy_cls; c++) nH += P.queue[4 + c];
-        const uint32_t N = (uint32_t)P.part.local_rows * (uint32_t)P.nx;
+        // the chains: list 0 (the launcher's threshold: pixels several times the mean) goes, `chain_lanes` pixels per wave, to the first waves that ask, and those
+        // waves take nothing else while these run (below); at most one wave in eight
+        uint32_t chain_lanes = (uint32_t)(leaf_thr >> 16) & 0xFFu;
+        uint32_t E = chain_lanes ? P.queue[4] : 0u;
+        if (E > nH) E = nH;
+        if (E > ((uint32_t)P.part.local_rows * (uint32_t)P.nx >> ((leaf_thr >> 24) & 0xF))) E = 0u;      // list 0 is not "a few pixels" in this scene (its threshold is absolute): no chain waves
+        const uint32_t max_waves = gridDim.x * (blockDim.x >> 6) >> 3;
+        if (E > max_waves * chain_lanes) chain_lanes = min(64u, (E + max_waves - 1u) / max_waves);      // (a long list: more of its pixels per wave, not fewer of them in chain waves)
+        if (E > max_waves * chain_lanes) E = max_waves * chain_lanes;
+        s_m[3] = chain_lanes;
+        const uint32_t N = (uint32_t)P.part.local_rows * (uint32_t)P.nx - E;
+        nH -= E;
         uint32_t S = (uint32_t)rounds * gridDim.x * blockDim.x;
         if (S > N) S = N;
         if (heavy_cls == 0 || rounds == 0 || nH == 0u || nH > S || S - nH > N - nH) { nH = 0u; S = 0u; }      // (off: the lists as they lie)
-        s_m[0] = nH; s_m[1] = S;
+        s_m[0] = nH; s_m[1] = S; s_m[2] = E;
     }
     if (PHASE == 2) __syncthreads();
+    const int chain_lanes = PHASE == 2 ? (int)s_m[3] : 0;
     leaf_thr &= 0xFF;
 
     // path state (path, helper_structs.h:48-71)
@@ -397,7 +426,8 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     uint32_t nrays = 0, nshadow = 0;
     uint32_t pix_jobs = 0;              // PHASE 1: node visits of this pixel so far: its measured cost
     const int s_end = PHASE == 1 ? P.s_split : P.ns;
-    const uint32_t n_items = PHASE == 2 ? (uint32_t)P.part.local_rows * (uint32_t)P.nx : total;      // the lists hold the valid pixels only
+    const uint32_t n_chain = PHASE == 2 ? s_m[2] : 0u;
+    const uint32_t n_items = PHASE == 2 ? (uint32_t)P.part.local_rows * (uint32_t)P.nx - n_chain : total;      // the lists hold the valid pixels only
     // diagnostics (P.dbg): cycles and active lanes per phase, per wave; summed over the waves at the end
     unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
@@ -429,6 +459,30 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
         stat(RT_STAT_PRIMARY);
         want_job = 1;                                               // hit(context, p, FLT_MAX, false, ...)
     };
+
+    auto resume_pixel = [&](uint32_t pos) {                          // PHASE 2: the pixel's stream continues where the first dispatch left it
+        const uint32_t packed = P.order[pos];
+        const float4 st4 = P.ord_state[pos];
+        pi = (int)(packed & 0xFFFFu); lr = (int)(packed >> 16);
+        pj = global_row(P.part, lr);
+        pixelId = (uint32_t)(pj * P.nx + pi);
+        rng = __float_as_uint(st4.w);
+        col = F3(st4.x, st4.y, st4.z);
+        s = P.s_split;
+        have_pixel = true;
+        need_sample = true;
+#if RT_MESH_TAIL_DIAG
+        g_diag_items[((size_t)lr * P.nx + pi) * 2] = (uint32_t)(__builtin_amdgcn_s_memrealtime() / 100ull);
+#endif
+    };
+    // Chain waves (PHASE 2).  The frame cannot end before its most expensive pixel has traced its 250 samples one after the other (the stream is
+    // sequential), and in a wave of 64 busy lanes a pixel advances only in the steps of its own kind (node / leaf) and waits through the others: measured,
+    // the ~60 most expensive pixels of C4 ended 100 ms after everything else (profiles/r04_mesh_tail_diag.txt).  So the first waves to ask take `chain_lanes`
+    // pixels of list 0 each and nothing else until those are done: few lanes, every step is theirs (leaf phase as soon as one lane waits, PROCESS as soon as one
+    // traversal ends); then the wave joins the others at the queue.
+    const int leaf_thr0 = leaf_thr, min_traversing0 = min_traversing;
+    bool chain_wave = false;                                         // (wave-uniform) holds pixels of list 0 only; when they are done it joins the others
+    bool chain_ask = PHASE == 2 && n_chain != 0u;                    // (asked at the first refill: a pixel is taken where the others are, after PROCESS)
 
     while (true) {
         // ================= PROCESS: lanes without a running traversal =======================================
@@ -576,12 +630,31 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                     // one 12-byte store (global_store_dwordx3): a lane finishes its pixel on its own, three dword stores are three partial-sector writes
                     *reinterpret_cast<float3*>(fbf + ((size_t)lr * P.nx + pi) * 3) = make_float3(out.x, out.y, out.z);
                     have_pixel = false;
+#if RT_MESH_TAIL_DIAG
+                    if (PHASE == 2) g_diag_items[((size_t)lr * P.nx + pi) * 2 + 1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() / 100ull);
+#endif
                 }
             }
         }
 
         if (dbg) { const unsigned long long c1 = __builtin_amdgcn_s_memtime(); g_cyc[0] += c1 - c0; c0 = c1; }
         // ================= refill idle lanes from the global pixel queue ======================================
+        if (PHASE == 2 && chain_ask) {
+            chain_ask = false;
+            uint32_t c = 0;
+            if ((threadIdx.x & 63) == 0) c = atomicAdd(P.queue + 1, (uint32_t)chain_lanes);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c < n_chain) {
+                chain_wave = true;
+                leaf_thr = 1; min_traversing = 63;
+                const uint32_t l = threadIdx.x & 63u;
+                if (l < (uint32_t)chain_lanes && c + l < n_chain) resume_pixel(c + l);
+            }
+        }
+        if (PHASE == 2 && chain_wave) {
+            if (__ballot(have_pixel) != 0ull) goto refilled;         // a chain wave takes nothing while a chain runs
+            chain_wave = false; leaf_thr = leaf_thr0; min_traversing = min_traversing0;
+        }
         while (!exhausted) {
             const unsigned long long need = __ballot(!have_pixel);
             if (need == 0ull) break;
@@ -592,6 +665,9 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
             if (base >= n_items) { exhausted = true; break; }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (base + cnt >= n_items) exhausted = true;
+#if RT_MESH_TAIL_DIAG
+            if (PHASE == 2 && exhausted && (threadIdx.x & 63) == 0) atomicMin(reinterpret_cast<unsigned long long*>(P.queue + 48), __builtin_amdgcn_s_memrealtime());      // the queue ran empty
+#endif
             if (!have_pixel && base + rank < n_items) {
                 if (PHASE == 2) {                                    // resume: the pixel's stream continues where the first dispatch left it
                     uint32_t pos = (stride == 0xFFFFFFFFu) ? n_items - 1u - (base + rank) : base + rank;      // (stride ~0: experiment, cheapest first)
@@ -603,16 +679,7 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                             pos = after > before ? before : nH + (pos - before);
                         }                                            // (pos >= S: every expensive pixel is out: the rest list at nH + (pos - nH) = pos)
                     }
-                    const uint32_t packed = P.order[pos];
-                    const float4 st4 = P.ord_state[pos];
-                    pi = (int)(packed & 0xFFFFu); lr = (int)(packed >> 16);
-                    pj = global_row(P.part, lr);
-                    pixelId = (uint32_t)(pj * P.nx + pi);
-                    rng = __float_as_uint(st4.w);
-                    col = F3(st4.x, st4.y, st4.z);
-                    s = P.s_split;
-                    have_pixel = true;
-                    need_sample = true;
+                    resume_pixel(n_chain + pos);
                 } else {
                 const uint32_t p = (uint32_t)(((unsigned long long)(base + rank) * stride) % total);
                 const uint32_t tile = p >> 6, within = p & 63u;
@@ -632,6 +699,7 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                 }
             }
         }
+    refilled:
         if (__ballot(have_pixel) == 0ull) break;
         if (need_sample) { start_sample(); need_sample = false; }    // one site for "path ended" and "new pixel"
         if (want_job) {
@@ -897,6 +965,13 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
             } while (__popcll(__ballot(have_pixel && J.idx != 0)) >= min_traversing);
         }
     }
+#if RT_MESH_TAIL_DIAG
+    if (PHASE == 2 && (threadIdx.x & 63) == 0) {                    // (diagnostic build: when did the queue run empty, when did the last wave end: tools/build_variant.sh -DRT_MESH_TAIL_DIAG=1)
+        atomicMin(reinterpret_cast<unsigned long long*>(P.queue + 50), t_start_diag);
+        atomicMax(reinterpret_cast<unsigned long long*>(P.queue + 52), __builtin_amdgcn_s_memrealtime());
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.queue + 54), __builtin_amdgcn_s_memrealtime() - t_start_diag);      // wave-time
+    }
+#endif
     if (dbg && (threadIdx.x & 63) == 0) {
         for (int k = 0; k < 4; k++) { atomicAdd(P.dbg + k, g_cyc[k]); atomicAdd(P.dbg + 4 + k, g_act[k]); atomicAdd(P.dbg + 8 + k, g_it[k]); }
         atomicAdd(P.dbg + 12, 1ull);
@@ -975,7 +1050,9 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
         if (e != hipSuccess) return e;
         RtSphereParams o;                                            // what the ordering pass reads (rt_params.h: rt_order_pixels_by_cost)
         memset(&o, 0, sizeof o);
-        o.nx = p.nx; o.ny = p.ny; o.part = p.part; o.s_split = split; o.chain_top_thr = 384;
+        const int chain_thr_env = getenv("RT_MESH_CHAIN_THR") ? atoi(getenv("RT_MESH_CHAIN_THR")) : RT_MESH_CHAIN_THR;
+        const int chain_lanes_env = getenv("RT_MESH_CHAIN_LANES") ? atoi(getenv("RT_MESH_CHAIN_LANES")) : RT_MESH_CHAIN_LANES;
+        o.nx = p.nx; o.ny = p.ny; o.part = p.part; o.s_split = split; o.chain_top_thr = chain_thr_env < 17 ? 17 : chain_thr_env;
         o.px_rays = p.px_rays; o.px_state = p.px_state; o.order = p.order; o.ord_state = p.ord_state; o.ord_rays = p.ord_rays; o.queue = p.queue;
         e = rt_order_pixels_by_cost(o, stream);
         if (e != hipSuccess) return e;
@@ -983,9 +1060,23 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
         static const int heavy_env = getenv("RT_MESH_HEAVY") ? atoi(getenv("RT_MESH_HEAVY")) : RT_MESH_HEAVY_CLS;       // expensive classes spread over the first fills
         static const int rounds_env = getenv("RT_MESH_ROUNDS") ? atoi(getenv("RT_MESH_ROUNDS")) : RT_MESH_SPREAD_ROUNDS;
         const uint32_t stride2 = rev_env ? 0xFFFFFFFFu : stride;
-        const int lt2 = leaf_thr | ((heavy_env & 0xF) << 8) | ((rounds_env & 0xF) << 12);
+        const int chain_frac = getenv("RT_MESH_CHAIN_FRAC") ? (atoi(getenv("RT_MESH_CHAIN_FRAC")) & 0xF) : 8;     // chain waves only while list 0 is below pixels >> this (tests: 0)
+        const int lt2 = leaf_thr | ((heavy_env & 0xF) << 8) | ((rounds_env & 0xF) << 12) | ((chain_lanes_env < 0 ? 0 : chain_lanes_env > 64 ? 64 : chain_lanes_env) << 16) | (chain_frac << 24);
+#if RT_MESH_TAIL_DIAG
+        static uint32_t* d_items = nullptr; const size_t n_px = (size_t)p.part.local_rows * p.nx;
+        if (!d_items) { (void)hipMalloc(&d_items, n_px * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_items), &d_items, sizeof d_items); }
+        { const unsigned long long init[4] = { ~0ull, ~0ull, 0ull, 0ull }; (void)hipMemcpyAsync(p.queue + 48, init, sizeof init, hipMemcpyHostToDevice, stream); (void)hipStreamSynchronize(stream); }
+#endif
         if (lean) hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, true, 2>), grid, block, lds, stream, q, stride2, min_traversing, lt2);
         else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, false, 2>), grid, block, lds, stream, q, stride2, min_traversing, lt2);
+#if RT_MESH_TAIL_DIAG
+        { unsigned long long r[4]; (void)hipStreamSynchronize(stream); (void)hipMemcpy(r, p.queue + 48, sizeof r, hipMemcpyDeviceToHost);
+          unsigned q4[2]; (void)hipMemcpy(q4, p.queue + 4, 4, hipMemcpyDeviceToHost); fprintf(stderr, "list 0: %u pixels; ", q4[0]);
+          fprintf(stderr, "mesh tail diag: queue empty at %.1f ms, last wave ends at %.1f ms, mean wave life %.1f ms (%u waves)\n", (double)(r[0] - r[1]) * 1e-5, (double)(r[2] - r[1]) * 1e-5,
+                  (double)r[3] * 1e-5 / ((double)grid.x * (block.x / 64)), grid.x * (block.x / 64));
+          if (const char* f = getenv("RT_MESH_DIAG_FILE")) { std::vector<uint32_t> h(n_px * 3); (void)hipMemcpy(h.data(), d_items, n_px * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data() + n_px * 2, p.px_rays, n_px * 4, hipMemcpyDeviceToHost); if (FILE* o = fopen(f, "wb")) { fwrite(h.data(), 4, h.size(), o); fclose(o); } } }
+#endif
         return hipGetLastError();
     }
     if (classic) {

@@ -325,5 +325,41 @@ def test_two_dispatch_cost_ordered_mesh_frame_bit_exact(rt, O, stair, textured):
         part = np.array(fb, copy=True)
         for k in range(r, (ny + 7) // 8, 3):
             merged[k * 8:(k + 1) * 8] = part[k * 8:(k + 1) * 8]
-    rt.cleanupRenderer()
     assert np.array_equal(_bits(merged), _bits(ref))
+    # chain waves (second dispatch: the most expensive pixels, a few per wave, in waves that take nothing else until they are done, then join the queue): with the
+    # list-0 threshold at its floor and the "few pixels only" guard off EVERY pixel goes through them - 1, 6 and (auto-raised) more pixels per wave - and with 0 none
+    import os
+    saved = {k: os.environ.get(k) for k in ("RT_MESH_CHAIN_THR", "RT_MESH_CHAIN_LANES", "RT_MESH_CHAIN_FRAC")}
+    try:
+        rt.setRenderOptions(o, part_rank=0, part_world=1, stripe_rows=8)
+        for thr, lanes, frac in ((17, 1, 0), (17, 6, 0), (17, 64, 0), (100, 3, 0), (448, 0, 8)):
+            os.environ.update(RT_MESH_CHAIN_THR=str(thr), RT_MESH_CHAIN_LANES=str(lanes), RT_MESH_CHAIN_FRAC=str(frac))
+            rt.runRenderer(ns, 8, 8)
+            assert np.array_equal(_bits(np.array(fb)), _bits(ref)), (thr, lanes, frac)
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    rt.cleanupRenderer()
+
+
+def test_full_size_c4_frame_two_dispatches_with_chain_waves_equals_single_dispatch(rt):
+    """BASELINE config C4's scene and frame (detail-4 staircase, 1920x1080, depth 64, NEE + RR) at 16 spp: the production frame - two dispatches, cost
+    order, expensive lists spread, the ~0.1 % most expensive pixels in chain waves with their real list-0 threshold - against the single scattered dispatch
+    of the counting instantiation (which the tests above hold to the oracle), bit for bit; its chain-less form too."""
+    import os
+    tris, mats = rt.scene_staircase_procedural(4)
+    hm = rt.HostMesh.build(tris, 5)
+    nx, ny, ns = 1920, 1080, 16
+    cam = rt.staircase_camera(nx, ny)
+    single, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64, counters=1)
+    two, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64)
+    assert np.array_equal(_bits(two), _bits(single)), np.count_nonzero(_bits(two) != _bits(single))
+    saved = os.environ.get("RT_MESH_CHAIN_LANES")
+    try:
+        os.environ["RT_MESH_CHAIN_LANES"] = "0"
+        plain, _ = _render_gpu(rt, hm, mats, cam, nx, ny, ns, 64)
+    finally:
+        if saved is None: os.environ.pop("RT_MESH_CHAIN_LANES", None)
+        else: os.environ["RT_MESH_CHAIN_LANES"] = saved
+    assert np.array_equal(_bits(plain), _bits(single))
