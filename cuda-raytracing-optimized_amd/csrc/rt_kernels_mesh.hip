@@ -38,7 +38,10 @@ using namespace rtd;
 
 namespace {
 
-constexpr int kWavesPerWg = 4;
+#ifndef RT_MESH_WG_WAVES
+#define RT_MESH_WG_WAVES 4          // waves per workgroup (experiment: 16 = one workgroup per CU, one LDS copy of the tables)
+#endif
+constexpr int kWavesPerWg = RT_MESH_WG_WAVES;
 constexpr int kThreads = 64 * kWavesPerWg;
 
 __device__ __forceinline__ int global_row(const RtPartition& pt, int lr) {
@@ -1011,7 +1014,7 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
                       p.nppl >= 1u && p.nppl <= 16u && p.first_leaf <= kLeafCntLds;
     if (wg_per_cu == 0) wg_per_cu = lean ? RT_MESH_LEAN_WAVES : (classic0 ? 5 : 4);   // = the launch bounds (96 / 128 VGPRs); the pair rounds spill at 96      // launch bound: 5 waves per SIMD (96 VGPRs); 6 gave the same rate, 8 spills
     const long long total_px = (long long)((p.nx + 7) / 8) * ((p.part.local_rows + 7) / 8) * 64;
-    long long blocks = (long long)cus * wg_per_cu;
+    long long blocks = (long long)cus * wg_per_cu * 4 / kWavesPerWg;
     const long long useful = (total_px + kThreads - 1) / kThreads;
     if (blocks > useful) blocks = useful;
     if (blocks < 1) blocks = 1;
