@@ -411,7 +411,7 @@ def main():
                                       "roofline": {k: v for k, v in sphere_roofline(j3, 1, committed_traffic("C3", 1200 * 800 * 12) if default_mode else None).items()
                                                    if k in ("bound", "achieved", "peak", "unit", "frac", "effective_frac", "executed_per_ray", "traffic", "traffic_over_algorithmic", "traffic_source")}})
             # C4: triangle mesh + BVH through the reference's own entry point
-            j4 = run_job(HipBackend(args.fp, "reference", 0), comm, WORKLOADS["C4"], 2, 1, tag, count_spp=4, warmup_spp=16)
+            j4 = run_job(HipBackend(args.fp, "reference", 0), comm, WORKLOADS["C4"], 3, 1, tag, count_spp=4, warmup_spp=16)
             w4 = WORKLOADS["C4"]
             others["C4"] = brief(j4, {"workload": w4["name"] + f", fp {args.fp}",
                                       "roofline": mesh_roofline(j4, 1, committed_traffic("C4", w4["nx"] * w4["ny"] * 12) if args.fp == "parity" else None)})
