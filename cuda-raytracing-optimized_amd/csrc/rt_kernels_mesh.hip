@@ -397,7 +397,10 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
         uint32_t chain_lanes = (uint32_t)(leaf_thr >> 16) & 0xFFu;
         uint32_t E = chain_lanes ? P.queue[4] : 0u;
         if (E > nH) E = nH;
-        if (E > ((uint32_t)P.part.local_rows * (uint32_t)P.nx >> ((leaf_thr >> 24) & 0xF))) E = 0u;      // list 0 is not "a few pixels" in this scene (its threshold is absolute): no chain waves
+        if (E > ((uint32_t)P.part.local_rows * (uint32_t)P.nx >> ((leaf_thr >> 24) & 0xF))) E = 0u;
+        // The chains end the frame only when a pixel of 10-20 x the mean (at about half the time per node visit of a cheap one) outlasts the whole queue, i.e. when
+        // the frame is less than ~16 fills of the machine (C4: 7.9; 3840x2160: 31.6 - chain waves measured -3 % there, +12 % on C4; profiles/r04_mesh_chain_scenes.txt)
+        if (((leaf_thr >> 24) & 0xF) != 0 && (uint32_t)P.part.local_rows * (uint32_t)P.nx > 16u * gridDim.x * blockDim.x) E = 0u;      // list 0 is not "a few pixels" in this scene (its threshold is absolute): no chain waves
         const uint32_t max_waves = gridDim.x * (blockDim.x >> 6) >> 3;
         if (E > max_waves * chain_lanes) chain_lanes = min(64u, (E + max_waves - 1u) / max_waves);      // (a long list: more of its pixels per wave, not fewer of them in chain waves)
         if (E > max_waves * chain_lanes) E = max_waves * chain_lanes;

@@ -19,10 +19,10 @@ for q in [50, 90, 99, 99.9]:
     print("cost >= p%s (%d): n %d, duration mean %.1f max %.1f ms; start mean %.1f; end max %.1f" % (q, th, m.sum(), du[m].mean(), du[m].max(), st[m].mean(), en[m].max()))
 m = st < 100
 print("corr(cost, duration | start<100ms) = %.3f" % np.corrcoef(cost[m], du[m])[0, 1])
-for T in [430, 450, 470, 490, 510, 530]:
+nx = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+for T in ([430, 450, 470, 490, 510, 530] if len(sys.argv) <= 2 else [round(en.max() * f, 1) for f in (0.7, 0.8, 0.85, 0.9, 0.95)]):
     m = en > T
     print("ending after %d ms: %d pixels; of them started before 10 ms: %d; start p50 %.1f; cost p50 %d" % (T, m.sum(), (m & (st < 10)).sum(), np.median(st[m]) if m.sum() else -1, np.median(cost[m]) if m.sum() else -1))
-m = en > 470
+m = en > (470 if len(sys.argv) <= 2 else en.max() * 0.9)
 idx = np.nonzero(m)[0][np.argsort(-en[m])][:40]
-nx = 1920
 for i in idx: print("  px (%4d,%4d) start %.1f dur %.1f end %.1f cost %d" % (i % nx, i // nx, st[i], du[i], en[i], cost[i]))
