@@ -1279,44 +1279,56 @@ constexpr int kOrderBlocks = 1024;
 
 template <int PASS>
 __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams P) {
-    __shared__ uint32_t s_cnt[kCostClasses], s_base[kCostClasses], s_start[kCostClasses], s_n[kCostClasses], s_stride[kCostClasses];
+    // One set of kCostClasses lists for the machine, or (P.xcd_queues == kXcdQueues) one set per XCD: list (x, c) = cost class c of the pixels that belong to XCD x
+    // (rt_xcd_of_pixel), counted into P.queue + x * kXcdQueueWords.  In P.order the sets lie one behind the other (XCD 0's lists, XCD 1's ...); word [3] of a
+    // queue block holds the first position of its set.
+    constexpr int kLists = kCostClasses * kXcdQueues;
+    __shared__ uint32_t s_cnt[kLists], s_base[kLists], s_start[kLists], s_n[kLists], s_stride[kLists];
+    const int xq = P.xcd_queues == kXcdQueues ? kXcdQueues : 1;
     const int tiles_x = (P.nx + 7) >> 3;
     const int tiles_y = (P.part.local_rows + 7) >> 3;
     const uint32_t total = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
     const uint32_t per = ((total + gridDim.x - 1u) / gridDim.x + (uint32_t)kThreads - 1u) / (uint32_t)kThreads * (uint32_t)kThreads;
     const uint32_t first = blockIdx.x * per, last = min(first + per, total);
     uint32_t packed = 0;                                             // (local row << 16) | column of the pixel class_of() looked at
-    auto class_of = [&](uint32_t p) {
+    auto class_of = [&](uint32_t p) {                                // list index x * kCostClasses + class, or -1
         const uint32_t tile = p >> 6, within = p & 63u;
         const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
         const int i = tx * 8 + (int)(within & 7u);
         const int lr = ty * 8 + (int)(within >> 3);
         packed = ((uint32_t)lr << 16) | (uint32_t)i;
-        return (p < last && i < P.nx && lr < P.part.local_rows) ? cost_class(P, i, lr) : -1;
+        if (!(p < last && i < P.nx && lr < P.part.local_rows)) return -1;
+        const int x = xq > 1 ? (int)rt_xcd_of_pixel((uint32_t)lr, (uint32_t)P.nx, (uint32_t)i) : 0;
+        return x * kCostClasses + cost_class(P, i, lr);
     };
-    if (threadIdx.x < kCostClasses) s_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < kLists) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t p = first + threadIdx.x; p < last; p += kThreads) {
         const int cls = class_of(p);
         if (cls >= 0) atomicAdd(&s_cnt[cls], 1u);
     }
     __syncthreads();
+    const int lx = (int)threadIdx.x / kCostClasses, lc = (int)threadIdx.x - lx * kCostClasses;      // the list this thread looks after
+    uint32_t* const Q = P.queue + (size_t)lx * kXcdQueueWords;
     if (PASS == 0) {
-        if (threadIdx.x < kCostClasses && s_cnt[threadIdx.x]) atomicAdd(P.queue + 4 + threadIdx.x, s_cnt[threadIdx.x]);
+        if ((int)threadIdx.x < xq * kCostClasses && s_cnt[threadIdx.x]) atomicAdd(Q + 4 + lc, s_cnt[threadIdx.x]);
         return;
     }
     // The list entries are written where the render kernel will read them: position = start + (rank x stride) mod n, the
     // multiplicative permutation that scatters neighbouring pixels over different waves (stride ~ 0.618 n, coprime with n;
     // 1 for the last, sky list), and hold the pixel as (local row << 16 | column) - so that fetching a pixel costs the render
     // kernel one load, not a 64-bit modulo and a division by the tile count.
-    if (threadIdx.x < kCostClasses) {
+    if ((int)threadIdx.x < xq * kCostClasses) {
         uint32_t start = 0;                                          // first position of this list in P.order
-        for (int c = 0; c < (int)threadIdx.x; c++) start += P.queue[4 + c];
-        const uint32_t n = P.queue[4 + threadIdx.x];
+        for (int x = 0; x < lx; x++)
+            for (int c = 0; c < kCostClasses; c++) start += P.queue[(size_t)x * kXcdQueueWords + 4 + c];
+        if (lc == 0) Q[3] = start;                                   // (every workgroup writes the same value)
+        for (int c = 0; c < lc; c++) start += Q[4 + c];
+        const uint32_t n = Q[4 + lc];
         s_start[threadIdx.x] = start;
         s_n[threadIdx.x] = n;
-        s_stride[threadIdx.x] = ((int)threadIdx.x == kCostClasses - 1) ? 1u : coprime_stride_of(n);
-        s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(P.queue + 4 + kCostClasses + threadIdx.x, s_cnt[threadIdx.x]) : 0u;   // first rank of this workgroup
+        s_stride[threadIdx.x] = (lc == kCostClasses - 1) ? 1u : coprime_stride_of(n);
+        s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(Q + 4 + kCostClasses + lc, s_cnt[threadIdx.x]) : 0u;   // first rank of this workgroup
         s_cnt[threadIdx.x] = 0u;
     }
     __syncthreads();
@@ -1326,9 +1338,14 @@ __global__ void __launch_bounds__(kThreads) k_order_by_cost(const RtSphereParams
             const uint32_t rank = s_base[cls] + atomicAdd(&s_cnt[cls], 1u);
             const uint32_t at = s_start[cls] + (uint32_t)(((unsigned long long)rank * s_stride[cls]) % s_n[cls]);
             const size_t px = (size_t)(packed >> 16) * P.nx + (packed & 0xFFFFu);
-            P.order[at] = packed;
-            P.ord_state[at] = P.px_state[px];                        // the parked state travels with the list entry (see RtSphereParams::ord_state)
-            P.ord_rays[at] = P.px_rays[px];
+            if (P.ord_rec) {                                         // one 32-byte record per queue position (RtSphereParams::ord_rec)
+                P.ord_rec[2 * (size_t)at] = P.px_state[px];
+                P.ord_rec[2 * (size_t)at + 1] = make_float4(__uint_as_float(packed), __uint_as_float(P.px_rays[px]), 0.0f, 0.0f);
+            } else {
+                P.order[at] = packed;
+                P.ord_state[at] = P.px_state[px];                    // the parked state travels with the list entry (see RtSphereParams::ord_state)
+                P.ord_rays[at] = P.px_rays[px];
+            }
         }
     }
 }
@@ -1377,34 +1394,48 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
     // Everything the refill needs about the lists lives in LDS (s_q), not in SGPRs: it is read once per refill.
     constexpr int n_cls = CLS == 2 ? kCostClasses : (CLS == 1 ? 3 : 0);
     __shared__ uint32_t s_cls_base[kCostClasses], s_cls_pos[kCostClasses + 1], s_cls_stride[kCostClasses];
-    __shared__ uint32_t s_q[8];       // [0] nA (chain-list pixels)  [1] n0 (heavy-list pixels)  [2] total items of the general queue  [3] spread  [4] spread_ok
-    if (threadIdx.x == 0) {
-        uint32_t pos = 0;
-        for (int c = 0; c < n_cls; c++) {
-            const uint32_t n = P.queue[4 + c];
-            s_cls_base[c] = CLS == 2 ? pos : (uint32_t)c * padded;
-            s_cls_pos[c] = pos;
-            s_cls_stride[c] = (c == n_cls - 1) ? 1u : coprime_stride_of(n);
-            pos += n;
-        }
-        for (int c = n_cls; c <= kCostClasses; c++) s_cls_pos[c] = pos;
+    // s_q: 8 words per queue - [0] nA (chain-list pixels)  [1] n0 (heavy-list pixels)  [2] total items of the general queue  [3] spread  [4] spread_ok  [5] middle tier on
+    // [6] first position of the queue's lists in P.order.  One queue for the machine, or (CLS = 2 with P.xcd_queues: RtSphereParams::xcd_queues) one per XCD: a wave
+    // serves the queue of the XCD it runs on (XCC_ID) and, when that is empty, the general queues of the others in turn (`stolen`); the list tables
+    // (s_cls_*) are those of the wave's own XCD - only its chain waves look at them.
+    __shared__ uint32_t s_q[8 * kXcdQueues];
+    const uint32_t xq = (CLS == 2 && P.xcd_queues == kXcdQueues) ? (uint32_t)kXcdQueues : 1u;
+    const uint32_t myx = xq > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & (uint32_t)(kXcdQueues - 1)) : 0u;       // XCC_ID
+    if (threadIdx.x < xq) {
+        const uint32_t x = threadIdx.x;
+        const uint32_t* const Q = P.queue + (size_t)x * kXcdQueueWords;
+        const uint32_t seg = CLS == 2 ? Q[3] : 0u;
         // CLS = 2 (tiered): lists [0, n_chain) are the chain lists, the lists up to kChainClasses + kHeavyClasses the
         // heavy lists, the remaining ones the rest.  CLS = 1: no chain lists; list 0 is the heavy list.
         const int n_chain = CLS == 2 ? ((chain_cfg >> 24) & 0xF) : 0;
-        const uint32_t nA = CLS == 2 ? s_cls_pos[n_chain] : 0u;
-        const uint32_t n0 = CLS == 2 ? s_cls_pos[kChainClasses + kHeavyClasses] - nA : (n_cls ? s_cls_pos[1] : 0u);   // heavy pixels
-        const uint32_t total_px = n_cls ? s_cls_pos[kCostClasses] - nA : padded;       // pixels in the general queue
+        const int n_heavy_end = CLS == 2 ? kChainClasses + kHeavyClasses : 1;
+        uint32_t pos = 0, nA = 0, n0 = 0;                            // nA: chain-list pixels; n0: heavy pixels
+        for (int c = 0; c < n_cls; c++) {
+            const uint32_t n = Q[4 + c];
+            if (x == myx) {
+                s_cls_base[c] = CLS == 2 ? seg + pos : (uint32_t)c * padded;
+                s_cls_pos[c] = pos;
+                s_cls_stride[c] = (CLS != 1 || c == n_cls - 1) ? 1u : coprime_stride_of(n);       // (CLS 2: the lists are stored permuted)
+            }
+            if (c < n_chain) nA += n; else if (c < n_heavy_end) n0 += n;
+            pos += n;
+        }
+        if (x == myx) for (int c = n_cls; c <= kCostClasses; c++) s_cls_pos[c] = pos;
+        const uint32_t total_px = n_cls ? pos - nA : padded;         // pixels in the general queue
         const uint32_t n_rest = total_px - n0;
-        // lanes that draw from the general queue at t = 0: all, minus the chain waves (which start on the chain lists)
-        uint32_t spread = gridDim.x * blockDim.x;
-        if (nA > 0u) spread -= ((gridDim.x + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u;
-        s_q[0] = nA; s_q[1] = n0; s_q[2] = total_px * (CHUNKED ? (uint32_t)P.chunks : 1u); s_q[3] = spread;
-        s_q[4] = (n0 > 0u && n0 <= spread && (spread - n0) <= n_rest) ? 1u : 0u;
+        // lanes that draw from the general queue at t = 0: all (of this XCD), minus the chain waves (which start on the chain lists)
+        const uint32_t wgs = xq > 1u ? max(gridDim.x / xq, 1u) : gridDim.x;
+        uint32_t spread = wgs * blockDim.x;
+        if (nA > 0u) spread -= min(spread - 64u, ((wgs + (uint32_t)(chain_cfg & 0xFF) - 1u) / (uint32_t)(chain_cfg & 0xFF)) * (uint32_t)((chain_cfg >> 8) & 0xF) * 64u);
+        uint32_t* const sq = s_q + 8 * x;
+        sq[0] = nA; sq[1] = n0; sq[2] = total_px * (CHUNKED ? (uint32_t)P.chunks : 1u); sq[3] = spread;
+        sq[4] = (n0 > 0u && n0 <= spread && (spread - n0) <= n_rest) ? 1u : 0u;
         // Middle tier (caps bits 16..19 = waves per workgroup, 20..27 = pixels such a wave holds; CLS = 2 only): the heavy lists are not spread over the normal
-        // waves but served, from their own counter (P.queue[2]), by "middle" waves that hold only a few pixels - see the role comment below.  The general
+        // waves but served, from their own counter (queue word [2]), by "middle" waves that hold only a few pixels - see the role comment below.  The general
         // queue is then the rest lists alone.
-        s_q[5] = 0u;
-        if (CLS == 2 && ((caps >> 16) & 0xF) != 0 && n0 > 0u) { s_q[5] = 1u; s_q[2] = n_rest; s_q[4] = 0u; }
+        sq[5] = 0u;
+        if (CLS == 2 && ((caps >> 16) & 0xF) != 0 && n0 > 0u) { sq[5] = 1u; sq[2] = n_rest; sq[4] = 0u; }
+        sq[6] = seg;
     }
     __syncthreads();
     // Chain waves.  A lane that is not boosted advances ONE ray per wave iteration, and an iteration takes 3-4 us for <= 4
@@ -1420,9 +1451,17 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
     // holds only `mid_cap` pixels runs the same dense form at about half the iteration time (the per-lane phases cost what they cost, the pair rounds shrink
     // with the rays): such pixels end in half the time for ~2.5x the cost per ray, on a few per cent of the frame's rays.
     int role = 2;
-    if (CLS == 2 && s_q[0] > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
-    else if (CLS == 2 && s_q[5] != 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) + ((caps >> 16) & 0xF)) role = 1;
+    if (CLS == 2 && s_q[8 * myx] > 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) && (blockIdx.x % (uint32_t)(chain_cfg & 0xFF)) == 0u) role = 0;
+    else if (CLS == 2 && s_q[8 * myx + 5] != 0u && (int)(threadIdx.x >> 6) < ((chain_cfg >> 8) & 0xF) + ((caps >> 16) & 0xF)) role = 1;
     const int mid_cap = (caps >> 20) & 0xFF;
+    // wave-uniform (a queue per XCD only): how far this wave has moved on from its own XCD's queue.  Even: it draws from the general queue of XCD
+    // (myx + stolen / 2) mod 8; odd: that general queue is empty and the wave (role 2) takes what is LEFT ON THAT QUEUE'S CHAIN LISTS.  Chain lists are served
+    // by the chain waves of their own XCD; but nothing promises that every XCD got a workgroup of this grid (a grid of six workgroups leaves two without), and
+    // at the end of a frame the other XCDs' waves have nothing else to do: they take the leftovers one pixel per grab, as pixels of the last chain class (the
+    // wave then holds at most that class's number of pixels, like a chain wave).
+    // (Kept as three plain values - xq, myx, stolen.  Packed into one word of bit fields the same logic cost 4.5 % of the frame in EVERY mode, with the same
+    // register counts: profiles/r04_ab_qstate.txt.)
+    uint32_t stolen = 0;
     int ccls = 7;                       // chain list (0 .. kChainClasses - 1) the lane's pixel came from (fetched while the wave had role 0), 7 = none.  A wave that
                                         // holds a pixel of list c holds at most caps[c] pixels (4 bits each)
 
@@ -1536,16 +1575,21 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
             // chain waves take ONE pixel per grab (cfg bit 1): all of them start together, so the grabs interleave and the head of the chain lists - the
             // longest estimates - is dealt one pixel to a wave instead of four neighbours of the list to the first wave that arrives
             const uint32_t cnt = (role == 0 && (cfg & 2)) ? 1u : (uint32_t)__popcll(need);
-            const uint32_t total = s_q[2];
+            const uint32_t qx = xq > 1u ? ((myx + (stolen >> 1)) & (uint32_t)(kXcdQueues - 1)) : 0u;      // the queue this wave draws from now
+            const uint32_t* const sq = s_q + 8 * qx;
+            const uint32_t total = sq[2];
             if (pool_next >= pool_end) {
                 // (PHASE 2, experiments: cfg bits 3..7 x 4 = positions a normal wave reserves at least per grab)
-                const uint32_t grab = (CHUNKED || PHASE == 1) ? max(cnt, 128u) : ((PHASE == 2 && role == 2) ? max(cnt, (uint32_t)((cfg >> 3) & 0x1F) * 4u) : cnt);
-                const uint32_t limit = role == 0 ? s_q[0] : (role == 1 ? s_q[1] : total);
+                const bool leftovers = (stolen & 1u) != 0u;             // (role 2 only)
+                const uint32_t grab = leftovers ? 1u : ((CHUNKED || PHASE == 1) ? max(cnt, 128u) : ((PHASE == 2 && role == 2) ? max(cnt, (uint32_t)((cfg >> 3) & 0x1F) * 4u) : cnt));
+                const uint32_t limit = (role == 0 || leftovers) ? sq[0] : (role == 1 ? sq[1] : total);
                 uint32_t b = 0;
-                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (role == 0 ? 1 : (role == 1 ? 2 : 0)), grab);
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(P.queue + (size_t)qx * kXcdQueueWords + ((role == 0 || leftovers) ? 1 : (role == 1 ? 2 : 0)), grab);
                 b = __builtin_amdgcn_readfirstlane(b);
                 if (b >= limit) {
                     if (role < 2) { role = 2; continue; }            // this wave's lists are empty: a normal wave from now on
+                    // a queue per XCD: this queue's general part is empty - what is left on its chain lists; that too - on to the next XCD's queue
+                    if (xq > 1u && stolen + 1u < 2u * xq) { stolen++; continue; }
                     exhausted = true;
                     break;
                 }
@@ -1556,28 +1600,33 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
             const uint32_t take = min(cnt, pool_end - pool_next);
             pool_next += take;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (role == 2 && pool_next >= total) exhausted = true;   // this grab took the last items
+            if (role == 2 && pool_next >= total && xq == 1u) exhausted = true;   // this grab took the last items (one queue for the machine; with a queue per XCD the failing grabs say so)
             if (!have_pixel && rank < take) {
                 const uint32_t item = base + rank;
                 uint32_t pos = item;                                 // position in the pixel order; the chunks of a pixel are adjacent items
                 if (CHUNKED) { pos = item / (uint32_t)P.chunks; chunk = (int)(item - pos * (uint32_t)P.chunks); }
                 uint32_t p, opos = 0;                                // opos: position in P.order (CLS 2): where the pixel's parked state lies as well
+                float4 rec0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // (P.ord_rec: the parked state and ray count came with the list entry)
+                uint32_t rec_rays = 0;
                 if (CLS == 0) {
                     // queue position -> pixel: a multiplicative permutation (stride coprime with total) scatters
                     // neighbouring pixels over different waves, so the few very long pixels (50-bounce paths in the wedge between a sphere and
                     // the ground, clustered along the contact line) never share a wave; stride 1 = tile-major order
-                    p = (uint32_t)(((unsigned long long)pos * stride) % padded);
+                    // (first dispatch, cfg bit 30: the permutation moves ROW SEGMENTS of a tile - 8 adjacent pixels stay together in 8 adjacent lanes, whose parked
+                    // states fill one 128-byte line of px_state; `stride` is then coprime with padded / 8)
+                    if (PHASE == 1 && (cfg & (1 << 30)) != 0) p = ((uint32_t)(((unsigned long long)(pos >> 3) * stride) % (padded >> 3)) << 3) | (pos & 7u);
+                    else p = (uint32_t)(((unsigned long long)pos * stride) % padded);
                 } else {
                     // the n0 pixels of the heavy lists are spread evenly over the first `spread` queue positions (= the lanes in
                     // flight at t = 0), so every wave starts with a few of them instead of a few waves with nothing
                     // else; position p is a heavy-list position iff floor((p+1) n0 / spread) > floor(p n0 / spread)
                     uint32_t q;                                      // position in the concatenation of all lists
-                    if (role == 0) q = pos;
-                    else if (role == 1) q = s_q[0] + pos;                                    // the heavy lists, in order (longest estimates first)
-                    else if (CLS == 2 && s_q[5] != 0u) q = s_q[0] + s_q[1] + pos;           // middle tier on: the general queue is the rest lists
+                    if (role == 0 || (stolen & 1u) != 0u) q = pos;                           // a chain-list position
+                    else if (role == 1) q = sq[0] + pos;                                    // the heavy lists, in order (longest estimates first)
+                    else if (CLS == 2 && sq[5] != 0u) q = sq[0] + sq[1] + pos;           // middle tier on: the general queue is the rest lists
                     else {
-                        const uint32_t nA = s_q[0], n0 = s_q[1], spread = s_q[3];
-                        const bool spread_ok = s_q[4] != 0u;
+                        const uint32_t nA = sq[0], n0 = sq[1], spread = sq[3];
+                        const bool spread_ok = sq[4] != 0u;
                         uint32_t i0, i1;
                         bool is0;
                         if (spread_ok && pos < spread) {
@@ -1591,13 +1640,21 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
                         }
                         q = nA + (is0 ? i0 : n0 + i1);
                     }
-                    int c = 0;
-                    for (int k = 1; k < n_cls; k++) if (q >= s_cls_pos[k]) c = k;
-                    const uint32_t j = q - s_cls_pos[c];
                     if (CLS == 2) {
-                        opos = s_cls_base[c] + j;
-                        p = P.order[opos];                           // already permuted, already (row << 16 | column): k_order_by_cost
+                        // the lists of a queue lie one behind the other in P.order: position = first position of the queue's lists + q, whichever list q falls into
+                        opos = sq[6] + q;
+                        if (P.ord_rec) {                             // one 32-byte record: parked state | pixel, rays (k_order_by_cost)
+                            rec0 = P.ord_rec[2 * (size_t)opos];
+                            const float4 rec1 = P.ord_rec[2 * (size_t)opos + 1];
+                            p = __float_as_uint(rec1.x);
+                            rec_rays = __float_as_uint(rec1.y);
+                        } else {
+                            p = P.order[opos];                       // already permuted, already (row << 16 | column): k_order_by_cost
+                        }
                     } else {
+                        int c = 0;
+                        for (int k = 1; k < n_cls; k++) if (q >= s_cls_pos[k]) c = k;
+                        const uint32_t j = q - s_cls_pos[c];
                         const uint32_t nc = s_cls_pos[c + 1] - s_cls_pos[c];
                         p = P.order[s_cls_base[c] + (uint32_t)(((unsigned long long)j * s_cls_stride[c]) % nc)];
                     }
@@ -1621,13 +1678,13 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
                         init_pixel(P, L, i, global_row(P.part, lr), 0);
                         pix_rays = 0;
                     } else {                                         // resume: the pixel's stream continues where phase 1 left it
-                        const float4 st4 = P.ord_state[opos];
+                        const float4 st4 = (CLS == 2 && P.ord_rec) ? rec0 : P.ord_state[opos];
                         L.i = i; L.j = global_row(P.part, lr);
                         L.pixelId = (uint32_t)(L.j * P.nx + i);
                         L.rng = __float_as_uint(st4.w);
                         L.col = F3(st4.x, st4.y, st4.z);
                         L.s = P.s_split;
-                        pix_rays = P.ord_rays[opos];
+                        pix_rays = (CLS == 2 && P.ord_rec) ? rec_rays : P.ord_rays[opos];
                         if (wdbg) { dbg_grab = (float)(__builtin_amdgcn_s_memrealtime() - dbg_t0) * 1e-5f; dbg_p1 = (float)pix_rays; }
                     }
                     need_sample = true;
@@ -1635,6 +1692,7 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
                     ccls = 7;
                     if (CLS == 2 && role == 0) { ccls = 0; for (int k = 1; k < kChainClasses; k++) if (pos >= s_cls_pos[k]) ccls = k; }
                     if (CLS == 2 && role == 1) ccls = 6;
+                    if (CLS == 2 && role == 2 && (stolen & 1u) != 0u) ccls = kChainClasses - 1;        // a chain pixel nobody had taken
                 }
             }
         }
@@ -1655,7 +1713,7 @@ __global__ void __launch_bounds__(kThreads, (LEAN & 4) ? 6 : 4) k_render_spheres
         // one ray).  Scheduling only: the lane consumes its own RNG stream in order, so results do not change.
         // (One call site for both: the scan is large and must not be inlined twice.)
         // (a wave of the middle tier is fast already: no boost steps while it holds such a pixel)
-        const int steps = (boost > 0 && __popcll(live_now) > sparse_max && !(CLS == 2 && s_q[5] != 0u && __ballot(have_pixel && ccls == 6) != 0ull)) ? 1 + boost : 1;
+        const int steps = (boost > 0 && __popcll(live_now) > sparse_max && !(CLS == 2 && s_q[8 * myx + 5] != 0u && __ballot(have_pixel && ccls == 6) != 0ull)) ? 1 + boost : 1;
         for (int x = 0; x < steps; x++) {
             bool sel = have_pixel;
             if (x > 0) {
@@ -2013,9 +2071,22 @@ static hipError_t launch_spheres(const RtSphereParams& p, int variant, hipStream
         p.nx <= 65535 && p.part.local_rows <= 65535) {                                   // list entries pack (row << 16 | column)
         RtSphereParams q = p;
         q.phase = 1; q.s_split = split;
-        e = launch_queue_kernel<1, 0, false>(q, nb, lds, hybrid, stream, stride, cfg, chain_cfg);
+        // (q.p1_tile_major 1: the two-sample items in tile-major order - a wave parks two adjacent 8x8 tiles, whole lines of px_state; 2: scattered as row
+        // segments of 8 pixels - a line of px_state per 8 lanes, the scattering kept)
+        uint32_t stride1 = stride;
+        int cfg1 = cfg;
+        if (q.p1_tile_major == 1) stride1 = 1u;
+        if (q.p1_tile_major == 2 && total_px > 512) {
+            auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
+            const unsigned long long segs = (unsigned long long)total_px >> 3;
+            unsigned long long cand = (unsigned long long)((double)segs * 0.6180339887) | 1ull;
+            while (gcd(cand, segs) != 1ull) cand += 2;
+            stride1 = (uint32_t)(cand % segs);
+            cfg1 |= 1 << 30;
+        }
+        e = launch_queue_kernel<1, 0, false>(q, nb, lds, hybrid, stream, stride1, cfg1, chain_cfg);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(p.queue, 0, 256, stream);
+        e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kXcdQueues * kXcdQueueWords, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_order_by_cost<0>, dim3(kOrderBlocks), dim3(kThreads), 0, stream, q);
         hipLaunchKernelGGL(k_order_by_cost<1>, dim3(kOrderBlocks), dim3(kThreads), 0, stream, q);

@@ -100,7 +100,20 @@ struct RtSphereParams {
     uint32_t* px_rays;          // local_rows * nx: rays traced by phase 1
     float4* ord_state;          // the same two, copied by the ordering pass into QUEUE order (index = position in `order`): a lane that fetches a pixel in phase 2
     uint32_t* ord_rays;         // reads its list entry, state and ray count with three independent loads (by pixel they hang behind the list entry: one more round trip)
+    // Traffic forms of the two-dispatch frame (round 4, NS-2; sphere launcher only - the mesh launcher leaves all three at 0):
+    float4* ord_rec;            // != nullptr: the ordering pass writes ONE 32-byte record per queue position instead of the three arrays above - (col.xyz, rng bits |
+                                // row << 16 | column, rays, 0, 0) at ord_rec[2 pos], [2 pos + 1]: one sector per pixel written and read, not three.  (Measured and dropped:
+                                // 24-byte records as three 8-byte pieces - 8 MB less per frame, the frame 4 % slower.)
+    int32_t xcd_queues;         // 8: one set of cost lists and queue counters per XCD (P.queue + 64 x, kXcdQueueWords); a pixel belongs to the XCD
+                                // ((local row * nx + column) >> 5) & 7, so the 32 pixels of three adjacent 128-byte framebuffer lines are finished by waves behind ONE
+                                // L2, which merges their 12-byte stores into whole lines (`fb` in device memory).  0 / 1: one queue for the machine
+    int32_t p1_tile_major;      // 1: the first dispatch hands out its two-sample items in tile-major order (a wave parks the pixels of two adjacent 8x8 tiles: its 16-byte
+                                // states fill whole lines) instead of scattered
 };
+constexpr int kXcdQueueWords = 64;      // words per queue block: [0] general counter [1] chain counter [2] middle-tier counter [3] first position of this XCD's lists in
+                                        // `order` [4 .. 4 + 18) list lengths [22 .. 22 + 18) fill cursors
+constexpr int kXcdQueues = 8;
+__host__ __device__ inline uint32_t rt_xcd_of_pixel(uint32_t local_row, uint32_t nx, uint32_t column) { return ((local_row * nx + column) >> 5) & 7u; }
 
 struct RtMeshParams {
     rt_camera cam;

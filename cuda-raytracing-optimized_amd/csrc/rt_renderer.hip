@@ -44,6 +44,16 @@ void hip_check(hipError_t result, const char* func, const char* file, int line) 
     exit(99);
 }
 
+// Defaults of the traffic forms of the sphere kernel's two-dispatch frame (see runRenderer; each has an environment switch of the same meaning for A/B runs)
+constexpr bool kDefaultOrdPacked = true;
+constexpr bool kDefaultXcdQueues = true;
+constexpr int kDefaultP1Tile = 2;
+constexpr bool kDefaultFbDirect = false;
+static bool env_flag(const char* name, bool dflt) {     // "0" = off, any other value = on, unset = dflt
+    const char* v = getenv(name);
+    return v ? v[0] != '0' : dflt;
+}
+
 struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -82,6 +92,7 @@ struct DeviceState {
     uint32_t* d_px_rays = nullptr;
     float4* d_ord_state = nullptr;      // ... and their copies in queue order (RtSphereParams::ord_state / ord_rays)
     uint32_t* d_ord_rays = nullptr;
+    float4* d_ord_rec = nullptr;        // ... or as one 32-byte record per queue position (RtSphereParams::ord_rec)
 };
 
 struct RenderContext {
@@ -156,7 +167,7 @@ void free_device(DeviceState& d) {
     fr(d.d_tris); fr(d.d_bvh); fr(d.d_bvh_axis); fr(d.d_leaf_tri); fr(d.d_leaf_ofs); fr(d.d_materials);
     for (float* t : d.d_tex) fr(t);
     fr(d.d_tex_data); fr(d.d_tex_width); fr(d.d_tex_height);
-    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays); fr(d.d_ord_state); fr(d.d_ord_rays);
+    fr(d.d_fb); fr(d.d_counters); fr(d.d_queue); fr(d.d_wave_dbg); fr(d.d_order); fr(d.d_partial); fr(d.d_px_state); fr(d.d_px_rays); fr(d.d_ord_state); fr(d.d_ord_rays); fr(d.d_ord_rec);
     fr(d.d_params);
     if (d.h_params) HIP_CHECK(hipHostFree(d.h_params));
     if (d.ev_start) HIP_CHECK(hipEventDestroy(d.ev_start));
@@ -238,12 +249,13 @@ void setup_devices() {
                 HIP_CHECK(hipMalloc((void**)&d.d_px_rays, d.fb_rows * c.nx * sizeof(uint32_t)));
                 HIP_CHECK(hipMalloc((void**)&d.d_ord_state, padded * sizeof(float4)));
                 HIP_CHECK(hipMalloc((void**)&d.d_ord_rays, padded * sizeof(uint32_t)));
+                if (c.is_spheres) HIP_CHECK(hipMalloc((void**)&d.d_ord_rec, padded * 2 * sizeof(float4)));
             }
         }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
         HIP_CHECK(hipMemset(d.d_counters, 0, sizeof(RtCounters)));
-        HIP_CHECK(hipMalloc((void**)&d.d_queue, 256));
-        HIP_CHECK(hipMemset(d.d_queue, 0, 256));
+        HIP_CHECK(hipMalloc((void**)&d.d_queue, sizeof(uint32_t) * kXcdQueues * kXcdQueueWords));          // one block of queue words per XCD (rt_params.h)
+        HIP_CHECK(hipMemset(d.d_queue, 0, sizeof(uint32_t) * kXcdQueues * kXcdQueueWords));
         c.devs.push_back(d);
     }
     HIP_CHECK(hipSetDevice(current));
@@ -654,7 +666,7 @@ void runRenderer(int ns, int tx, int ty) {
         if (c.opt.counters) HIP_CHECK(hipMemsetAsync(d.d_counters, 0, sizeof(RtCounters), d.stream));
         // Finished pixels of the default sphere kernel go straight to the pinned host framebuffer (12 bytes each, spread over the whole frame time):
         // no device-to-host copy after the kernel.  RT_FB_DIRECT=0 keeps the compact device buffer + copy (every other kernel always does).
-        static const bool fb_direct_env = !(getenv("RT_FB_DIRECT") && getenv("RT_FB_DIRECT")[0] == '0');
+        const bool fb_direct_env = env_flag("RT_FB_DIRECT", kDefaultFbDirect);
         int spw = ns, chunks = 1;               // sphere path, RT_RNG_COUNTER: samples per work item, work items per pixel
         if (c.is_spheres && c.opt.rng == RT_RNG_COUNTER && (c.opt.variant & 0xFF) == 0) {
             // default: 4 samples per item, but no more items than fill and balance the machine (~32 M): a 3840x2160x4096spp frame cut into 4-sample items
@@ -703,6 +715,13 @@ void runRenderer(int ns, int tx, int ty) {
             p.phase = 0; p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays; p.ord_state = d.d_ord_state; p.ord_rays = d.d_ord_rays;
             static const int top_thr_env = getenv("RT_TOP_THR") ? atoi(getenv("RT_TOP_THR")) : 0;      // experiments
             p.chain_top_thr = top_thr_env >= 320 ? top_thr_env : 384;                                 // 24 rays per sample
+            // Traffic forms of the two-dispatch frame (RtSphereParams::ord_rec / xcd_queues / p1_tile_major; A/B switches read per frame, defaults = what measured best)
+            const bool ord_packed_env = env_flag("RT_ORD_PACKED", kDefaultOrdPacked);
+            const bool xcd_queues_env = env_flag("RT_XCD_QUEUES", kDefaultXcdQueues);
+            const int p1_tile_env = getenv("RT_P1_TILE") ? atoi(getenv("RT_P1_TILE")) : kDefaultP1Tile;     // 0 scattered, 1 tile-major, 2 scattered row segments
+            p.ord_rec = ord_packed_env ? d.d_ord_rec : nullptr;
+            p.xcd_queues = xcd_queues_env ? kXcdQueues : 0;
+            p.p1_tile_major = (p1_tile_env >= 0 && p1_tile_env <= 2) ? p1_tile_env : 0;
             if (chunks > 1) {
                 const size_t need = d.fb_rows * c.nx * (size_t)p.chunks * sizeof(rt_vec3);
                 if (need > d.partial_bytes) {
@@ -777,10 +796,12 @@ void runRenderer(int ns, int tx, int ty) {
         const size_t full = d.fb_rows / sr, rem = d.fb_rows % sr;
         char* dst0 = reinterpret_cast<char*>(c.h_ext ? c.h_ext : c.h_fb) + (size_t)part.rank * stripe_bytes;
         const char* src0 = reinterpret_cast<const char*>(d.d_fb);
-        if (full > 0 && !fb_direct)
+        if (world == 1) {                                               // the whole image: one linear copy
+            if (!fb_direct) HIP_CHECK(hipMemcpyAsync(dst0, src0, d.fb_rows * row_bytes, hipMemcpyDeviceToHost, d.stream));
+        } else if (full > 0 && !fb_direct)
             HIP_CHECK(hipMemcpy2DAsync(dst0, (size_t)world * stripe_bytes, src0, stripe_bytes, stripe_bytes, full,
                                        hipMemcpyDeviceToHost, d.stream));
-        if (rem > 0 && !fb_direct)
+        if (world != 1 && rem > 0 && !fb_direct)
             HIP_CHECK(hipMemcpyAsync(dst0 + full * (size_t)world * stripe_bytes, src0 + full * stripe_bytes, rem * row_bytes,
                                      hipMemcpyDeviceToHost, d.stream));
         samples += (int64_t)d.fb_rows * c.nx * ns;

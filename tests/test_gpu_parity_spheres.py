@@ -57,6 +57,50 @@ def test_two_dispatch_cost_ordered_frame_bit_exact(rt, O):
         assert st.rays == cnt.rays, variant
 
 
+@pytest.mark.parametrize("nx,ny,ns,world", [(480, 320, 12, 1), (61, 37, 9, 1), (96, 64, 10, 1), (333, 200, 8, 3), (1200, 96, 10, 1)])
+def test_traffic_forms_of_the_two_dispatch_frame_bit_exact(rt, O, nx, ny, ns, world, monkeypatch):
+    """The traffic forms of the two-dispatch frame (RtSphereParams::ord_rec / xcd_queues / p1_tile_major, DESIGN.md 3.8): 32-byte parked records in queue
+    order, one set of cost lists and queue counters per XCD (a wave serves the queue of the XCD it runs on, then steals from the others), a tile-major
+    first dispatch, and the finished pixels stored into the compact DEVICE framebuffer (RT_FB_DIRECT=0: whole lines leave the L2, the copy engine delivers
+    rows) - each alone and all together: the same bits as the oracle, every pixel written (NaN poison), the oracle's ray count.  61x37 launches three
+    workgroups and 96x64 six: at most that many XCDs have a wave, the queues of the others - chain lists included (96x64 has a chain pixel on XCD 6's) - are
+    emptied by the other XCDs' waves alone."""
+    sp, mt, cam = rt.scene_random_spheres(nx, ny)
+    ref, cnt = O.render(O.sphere_scene(sp, mt), cam, O.default_options(True), nx, ny, ns, 50, counters=True)
+    off = {"RT_ORD_PACKED": "0", "RT_XCD_QUEUES": "0", "RT_P1_TILE": "0", "RT_FB_DIRECT": "1"}
+    singles = [{"RT_ORD_PACKED": "1"}, {"RT_XCD_QUEUES": "1"}, {"RT_P1_TILE": "1"}, {"RT_P1_TILE": "2"}, {"RT_FB_DIRECT": "0"}]
+    combos = [{}] + singles + [{"RT_XCD_QUEUES": "1", "RT_FB_DIRECT": "0"}, {"RT_ORD_PACKED": "1", "RT_XCD_QUEUES": "1"},
+                               {"RT_ORD_PACKED": "1", "RT_XCD_QUEUES": "1", "RT_P1_TILE": "1", "RT_FB_DIRECT": "0"},
+                               {"RT_ORD_PACKED": "1", "RT_XCD_QUEUES": "1", "RT_P1_TILE": "2", "RT_FB_DIRECT": "0"},
+                               {"RT_ORD_PACKED": "1", "RT_XCD_QUEUES": "1", "RT_P1_TILE": "2", "RT_FB_DIRECT": "1"}]
+    for combo in combos:
+        for n in off:
+            monkeypatch.setenv(n, combo.get(n, off[n]))
+        fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, 50)
+        o = rt.getDefaultRenderOptions(True)
+        rays = 0
+        for frame in range(2):                                       # (twice: the queue words and records of the first frame are behind the second)
+            fb[:] = 0
+            rays = 0
+            for r in range(world):
+                rt.setRenderOptions(o, counters=1, part_rank=r, part_world=world)
+                rt.runRenderer(ns, 8, 8)
+                rays += rt.getRenderStats().rays
+            got = np.array(fb, copy=True)
+            assert not np.isnan(got).any(), (combo, frame)
+            assert np.array_equal(_bits(got), _bits(ref)), (combo, frame, np.count_nonzero(_bits(got) != _bits(ref)))
+        rt.cleanupRenderer()
+        assert rays == cnt.rays, combo
+        # the production kernels (no counters: the lean instantiations), same forms
+        fb = rt.initRendererSpheres(sp, mt, cam, nx, ny, 50)
+        for r in range(world):
+            rt.setRenderOptions(o, counters=0, part_rank=r, part_world=world)
+            rt.runRenderer(ns, 8, 8)
+        got = np.array(fb, copy=True)
+        rt.cleanupRenderer()
+        assert np.array_equal(_bits(got), _bits(ref)), (combo, "production", np.count_nonzero(_bits(got) != _bits(ref)))
+
+
 def test_random_spheres_options_bit_exact(rt, O):
     """Russian roulette, constant sky, counter RNG, shallow depth: each option against the oracle."""
     nx, ny, ns = 96, 64, 4
