@@ -126,8 +126,8 @@ class HipBackend:
                             rng=rt.RT_RNG_COUNTER if self.rng == "counter" else rt.RT_RNG_REFERENCE_STREAM,
                             variant=self.variant, part_rank=rank, part_world=world, stripe_rows=8)
         if shared_fb is not None:
-            rt.setExternalFramebuffer(shared_fb)     # every rank delivers its stripes into the one shared framebuffer (finished pixels are stored
-                                                     # straight into it over the bus; the kernels without direct delivery copy their stripes into it)
+            rt.setExternalFramebuffer(shared_fb)     # every rank delivers its stripes into the one shared framebuffer (copied from its compact device
+                                                     # framebuffer behind the kernel; RT_FB_DIRECT=1: finished pixels stored straight into it over the bus)
 
     def step(self, spp=None):
         self.rt.runRenderer(spp or self.w["spp"], 8, 8)      # blocking: kernel(s) incl. the delivery of this rank's stripes = the host gather

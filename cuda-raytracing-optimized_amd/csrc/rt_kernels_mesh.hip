@@ -344,7 +344,8 @@ __device__ uint32_t* g_diag_items;      // per pixel: (start, end) of its second
 #define RT_MESH_LEAN_WAVES 4
 #endif
 // PHASE (the cost-ordered frame, rt_params.h): 0 = whole pixels in one dispatch (scattered order); 1 = samples [0, s_split) of every pixel, then park the pixel;
-// 2 = resume the parked pixels in the order of P.order (longest first).  A frame ends one pixel-time after its queue runs empty, and a pixel of C4 is 1/8 of a
+// 2 = resume the parked pixels in the order of P.order (longest first; since round 4 from one set of lists and counters per XCD, with 32-byte records - the sphere
+// kernel's traffic forms, DESIGN.md 3.8: here they halve the reads of the parked state, the writes still leave the L2 as partial lines).  A frame ends one pixel-time after its queue runs empty, and a pixel of C4 is 1/8 of a
 // lane's frame: in scattered order the 1920x1080x256 frame ran at 782 Msamples/s where the same samples as a 3840x2160x64 frame ran at 1106
 // (profiles/r04_mesh_tail_probe.txt) - the expensive pixels were still running when everything else was done.
 template <int TRAV, bool DBG, bool STATS, bool LEAN = false, int PHASE = 0>
@@ -387,30 +388,40 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     // full of long traversals makes each of them ~1.5x longer, and the frame ends with them.  So the expensive lists (the first `heavy_cls` classes: nH pixels)
     // are SPREAD evenly over the first S queue positions, S = spread_rounds x (lanes in flight): position p takes an expensive pixel iff floor((p + 1) nH / S) >
     // floor(p nH / S), else the next of the rest (also by descending cost).  (leaf_thr >> 8: heavy_cls | spread_rounds << 4, from the launcher.)
-    __shared__ uint32_t s_m[4];         // [0] nH  [1] S  (PHASE 2)
-    if (PHASE == 2 && threadIdx.x == 0) {
+    // One set of lists and counters for the machine, or (P.xcd_queues, as in the sphere kernel: rt_params.h) one per XCD: a wave serves the queue of the XCD it runs
+    // on - the numbers below are then those of that XCD's lists and of an eighth of the grid - and when that is empty takes what the others have left (s_mx, `stolen`).
+    __shared__ uint32_t s_m[4];         // [0] nH  [1] S  [2] E  [3] chain lanes (PHASE 2; of this wave's own queue)
+    __shared__ uint32_t s_mx[8 * kXcdQueues];      // per queue: [0] nH [1] S [2] E [4] first position of its lists in P.order [5] items of its general part
+    const uint32_t xq = (PHASE == 2 && P.xcd_queues == kXcdQueues) ? (uint32_t)kXcdQueues : 1u;
+    const uint32_t myx = xq > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & (uint32_t)(kXcdQueues - 1)) : 0u;       // XCC_ID
+    if (PHASE == 2 && threadIdx.x < xq) {
+        const uint32_t* const Q = P.queue + (size_t)threadIdx.x * kXcdQueueWords;
+        const uint32_t grid_x = xq > 1u ? max(gridDim.x / xq, 1u) : gridDim.x;      // workgroups that serve this queue first
+        uint32_t pixels = 0;
+        for (int c = 0; c < 18; c++) pixels += Q[4 + c];
         const int heavy_cls = (leaf_thr >> 8) & 0xF, rounds = (leaf_thr >> 12) & 0xF;
         uint32_t nH = 0;
-        for (int c = 0; c < heavy_cls; c++) nH += P.queue[4 + c];
+        for (int c = 0; c < heavy_cls; c++) nH += Q[4 + c];
         // the chains: list 0 (the launcher's threshold: pixels several times the mean) goes, `chain_lanes` pixels per wave, to the first waves that ask, and those
         // waves take nothing else while these run (below); at most one wave in eight
         uint32_t chain_lanes = (uint32_t)(leaf_thr >> 16) & 0xFFu;
-        uint32_t E = chain_lanes ? P.queue[4] : 0u;
+        uint32_t E = chain_lanes ? Q[4] : 0u;
         if (E > nH) E = nH;
-        if (E > ((uint32_t)P.part.local_rows * (uint32_t)P.nx >> ((leaf_thr >> 24) & 0xF))) E = 0u;
+        if (E > (pixels >> ((leaf_thr >> 24) & 0xF))) E = 0u;
         // The chains end the frame only when a pixel of 10-20 x the mean (at about half the time per node visit of a cheap one) outlasts the whole queue, i.e. when
         // the frame is less than ~16 fills of the machine (C4: 7.9; 3840x2160: 31.6 - chain waves measured -3 % there, +12 % on C4; profiles/r04_mesh_chain_scenes.txt)
         if (((leaf_thr >> 24) & 0xF) != 0 && (uint32_t)P.part.local_rows * (uint32_t)P.nx > 16u * gridDim.x * blockDim.x) E = 0u;      // list 0 is not "a few pixels" in this scene (its threshold is absolute): no chain waves
-        const uint32_t max_waves = gridDim.x * (blockDim.x >> 6) >> 3;
+        const uint32_t max_waves = grid_x * (blockDim.x >> 6) >> 3;
         if (E > max_waves * chain_lanes) chain_lanes = min(64u, (E + max_waves - 1u) / max_waves);      // (a long list: more of its pixels per wave, not fewer of them in chain waves)
         if (E > max_waves * chain_lanes) E = max_waves * chain_lanes;
-        s_m[3] = chain_lanes;
-        const uint32_t N = (uint32_t)P.part.local_rows * (uint32_t)P.nx - E;
+        const uint32_t N = pixels - E;
         nH -= E;
-        uint32_t S = (uint32_t)rounds * gridDim.x * blockDim.x;
+        uint32_t S = (uint32_t)rounds * grid_x * blockDim.x;
         if (S > N) S = N;
         if (heavy_cls == 0 || rounds == 0 || nH == 0u || nH > S || S - nH > N - nH) { nH = 0u; S = 0u; }      // (off: the lists as they lie)
-        s_m[0] = nH; s_m[1] = S; s_m[2] = E;
+        uint32_t* const sm = s_mx + 8 * threadIdx.x;
+        sm[0] = nH; sm[1] = S; sm[2] = E; sm[4] = xq > 1u ? Q[3] : 0u; sm[5] = N;
+        if (threadIdx.x == myx) { s_m[0] = nH; s_m[1] = S; s_m[2] = E; s_m[3] = chain_lanes; }
     }
     if (PHASE == 2) __syncthreads();
     const int chain_lanes = PHASE == 2 ? (int)s_m[3] : 0;
@@ -433,7 +444,13 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     uint32_t pix_jobs = 0;              // PHASE 1: node visits of this pixel so far: its measured cost
     const int s_end = PHASE == 1 ? P.s_split : P.ns;
     const uint32_t n_chain = PHASE == 2 ? s_m[2] : 0u;
-    const uint32_t n_items = PHASE == 2 ? (uint32_t)P.part.local_rows * (uint32_t)P.nx - n_chain : total;      // the lists hold the valid pixels only
+    const uint32_t n_items = PHASE == 2 ? s_mx[8 * myx + 5] : total;      // the lists hold the valid pixels only
+    const uint32_t seg_own = PHASE == 2 ? s_mx[8 * myx + 4] : 0u;          // first position of this wave's own lists in P.order
+    uint32_t* const Qown = P.queue + (size_t)myx * kXcdQueueWords;
+    uint32_t stolen = 0;                // (a queue per XCD) stages beyond this wave's own general queue known to be empty: stage 2k + 1 = what is left of the chain
+                                        // pixels of queue (myx + k) mod 8, stage 2k + 2 = the general part of queue (myx + k + 1) mod 8
+    const bool p1seg = PHASE == 1 && (min_traversing & 256) != 0;      // first dispatch: the permutation moves row segments of 8 pixels (a line of px_state per 8 lanes)
+    min_traversing &= 255;
     // diagnostics (P.dbg): cycles and active lanes per phase, per wave; summed over the waves at the end
     unsigned long long g_cyc[4] = { 0, 0, 0, 0 };   // process, refill, node loop, leaf
     unsigned long long g_act[4] = { 0, 0, 0, 0 }, g_it[4] = { 0, 0, 0, 0 };   // active lanes summed over steps; steps
@@ -467,8 +484,15 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
     };
 
     auto resume_pixel = [&](uint32_t pos) {                          // PHASE 2: the pixel's stream continues where the first dispatch left it
-        const uint32_t packed = P.order[pos];
-        const float4 st4 = P.ord_state[pos];
+        uint32_t packed;
+        float4 st4;
+        if (P.ord_rec) {                                             // one 32-byte record per queue position (RtSphereParams::ord_rec)
+            st4 = P.ord_rec[2 * (size_t)pos];
+            packed = __float_as_uint(P.ord_rec[2 * (size_t)pos + 1].x);
+        } else {
+            packed = P.order[pos];
+            st4 = P.ord_state[pos];
+        }
         pi = (int)(packed & 0xFFFFu); lr = (int)(packed >> 16);
         pj = global_row(P.part, lr);
         pixelId = (uint32_t)(pj * P.nx + pi);
@@ -648,13 +672,13 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
         if (PHASE == 2 && chain_ask) {
             chain_ask = false;
             uint32_t c = 0;
-            if ((threadIdx.x & 63) == 0) c = atomicAdd(P.queue + 1, (uint32_t)chain_lanes);
+            if ((threadIdx.x & 63) == 0) c = atomicAdd(Qown + 1, (uint32_t)chain_lanes);
             c = __builtin_amdgcn_readfirstlane(c);
             if (c < n_chain) {
                 chain_wave = true;
                 leaf_thr = 1; min_traversing = 63;
                 const uint32_t l = threadIdx.x & 63u;
-                if (l < (uint32_t)chain_lanes && c + l < n_chain) resume_pixel(c + l);
+                if (l < (uint32_t)chain_lanes && c + l < n_chain) resume_pixel(seg_own + c + l);
             }
         }
         if (PHASE == 2 && chain_wave) {
@@ -666,7 +690,7 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
             if (need == 0ull) break;
             const uint32_t cnt = (uint32_t)__popcll(need);
             uint32_t base = 0;
-            if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue, cnt);
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(Qown, cnt);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n_items) { exhausted = true; break; }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -685,9 +709,11 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                             pos = after > before ? before : nH + (pos - before);
                         }                                            // (pos >= S: every expensive pixel is out: the rest list at nH + (pos - nH) = pos)
                     }
-                    resume_pixel(n_chain + pos);
+                    resume_pixel(seg_own + n_chain + pos);
                 } else {
-                const uint32_t p = (uint32_t)(((unsigned long long)(base + rank) * stride) % total);
+                const uint32_t it = base + rank;
+                const uint32_t p = p1seg ? (((uint32_t)(((unsigned long long)(it >> 3) * stride) % (total >> 3)) << 3) | (it & 7u))
+                                         : (uint32_t)(((unsigned long long)it * stride) % total);
                 const uint32_t tile = p >> 6, within = p & 63u;
                 const int ty = (int)(tile / (uint32_t)tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)tiles_x);
                 const int i = tx * 8 + (int)(within & 7u);
@@ -703,6 +729,36 @@ __global__ void __launch_bounds__(kThreads, LEAN ? RT_MESH_LEAN_WAVES : (TRAV ==
                     need_sample = true;
                 }
                 }
+            }
+        }
+        // (a queue per XCD) this wave's own queue is empty and lanes are idle: what the other stages have left - chain pixels nobody took (an XCD without a
+        // workgroup of this grid has nobody to take them), then the next XCD's general part, its chain pixels, ... - as ordinary pixels
+        while (PHASE == 2 && xq > 1u && exhausted && stolen + 1u < 2u * xq) {
+            const unsigned long long need = __ballot(!have_pixel);
+            if (need == 0ull) break;
+            const uint32_t cnt = (uint32_t)__popcll(need);
+            const uint32_t stage = stolen + 1u;
+            const uint32_t qx = (myx + (stage >> 1)) & (uint32_t)(kXcdQueues - 1);
+            const bool leftovers = (stage & 1u) != 0u;
+            const uint32_t* const sm = s_mx + 8 * qx;
+            const uint32_t limit = leftovers ? sm[2] : sm[5];
+            uint32_t base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(P.queue + (size_t)qx * kXcdQueueWords + (leftovers ? 1 : 0), cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= limit) { stolen = stage; continue; }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!have_pixel && base + rank < limit) {
+                uint32_t pos = base + rank;
+                if (!leftovers) {
+                    const uint32_t nH = sm[0], S = sm[1];
+                    if (nH != 0u && pos < S) {
+                        const uint32_t before = (uint32_t)(((unsigned long long)pos * nH) / S);
+                        const uint32_t after = (uint32_t)(((unsigned long long)(pos + 1u) * nH) / S);
+                        pos = after > before ? before : nH + (pos - before);
+                    }
+                    pos += sm[2];
+                }
+                resume_pixel(sm[4] + pos);
             }
         }
     refilled:
@@ -1048,11 +1104,22 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
         p.ns >= 4 * split && p.nx <= 65535 && p.part.local_rows <= 65535) {
         RtMeshParams q = p;
         q.s_split = split;
-        if (lean) hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, true, 1>), grid, block, lds, stream, q, stride, min_traversing, leaf_thr);
-        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, false, 1>), grid, block, lds, stream, q, stride, min_traversing, leaf_thr);
+        // (p.p1_segments: the first dispatch scatters row segments of 8 pixels - `stride` coprime with total / 8, flag in bit 8 of min_traversing)
+        uint32_t stride1 = stride;
+        int mt1 = min_traversing;
+        if (p.p1_segments && total_px > 512 && !tile_order) {
+            auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
+            const unsigned long long segs = (unsigned long long)total_px >> 3;
+            unsigned long long cand = (unsigned long long)((double)segs * 0.6180339887) | 1ull;
+            while (gcd(cand, segs) != 1ull) cand += 2;
+            stride1 = (uint32_t)(cand % segs);
+            mt1 |= 256;
+        }
+        if (lean) hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, true, 1>), grid, block, lds, stream, q, stride1, mt1, leaf_thr);
+        else hipLaunchKernelGGL((k_render_mesh_queue<0, false, false, false, 1>), grid, block, lds, stream, q, stride1, mt1, leaf_thr);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(p.queue, 0, 256, stream);
+        e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kXcdQueues * kXcdQueueWords, stream);
         if (e != hipSuccess) return e;
         RtSphereParams o;                                            // what the ordering pass reads (rt_params.h: rt_order_pixels_by_cost)
         memset(&o, 0, sizeof o);
@@ -1060,6 +1127,7 @@ hipError_t RT_LAUNCH_NAME(const RtMeshParams& p, int variant, hipStream_t stream
         const int chain_lanes_env = getenv("RT_MESH_CHAIN_LANES") ? atoi(getenv("RT_MESH_CHAIN_LANES")) : RT_MESH_CHAIN_LANES;
         o.nx = p.nx; o.ny = p.ny; o.part = p.part; o.s_split = split; o.chain_top_thr = chain_thr_env < 17 ? 17 : chain_thr_env;
         o.px_rays = p.px_rays; o.px_state = p.px_state; o.order = p.order; o.ord_state = p.ord_state; o.ord_rays = p.ord_rays; o.queue = p.queue;
+        o.ord_rec = p.ord_rec; o.xcd_queues = p.xcd_queues;
         e = rt_order_pixels_by_cost(o, stream);
         if (e != hipSuccess) return e;
         static const bool rev_env = getenv("RT_MESH_REV") && getenv("RT_MESH_REV")[0] == '1';       // experiment: cheapest pixels first

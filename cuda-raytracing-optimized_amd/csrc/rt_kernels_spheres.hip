@@ -32,9 +32,13 @@
 //   * scenes whose small spheres rest on a horizontal plane (the benchmark) run the box tests behind a cell-table prefilter (group_needs_cells): the part of the ray
 //     inside the spheres' slab has a bounding rectangle, per-cell sets of "boxes that begin below / end above" leave the 2-3 boxes it can overlap, and only those
 //     take the slab test - conservative on its own terms, so the pair set and the frame are unchanged;
-//   * framebuffer: the persistent kernels (default) store a finished pixel with ONE 12-byte store from the lane that owns it
-//     (pixels finish one by one, in cost order) - by default straight into the pinned host framebuffer (RtSphereParams::fb_global_rows);
-//     only the tile kernel (variant 1) transposes its 8x8 tile through LDS so that a wave writes row-contiguous dwords;
+//   * framebuffer: the persistent kernels (default) store a finished pixel with ONE 12-byte store from the lane that owns it (pixels finish one by
+//     one, in cost order) into the compact DEVICE framebuffer, and the two-dispatch frame sees to it that whole lines leave the L2: the cost lists and
+//     queue counters exist once per XCD, a pixel belongs to the XCD rt_xcd_of_pixel() names - the 32 pixels of three adjacent 128-byte lines to the same
+//     one - and a wave serves the queue of the XCD it runs on (then the others'), so the write-back L2 of that XCD merges the 12-byte stores; the copy
+//     engine delivers the rows to the host framebuffer (RT_FB_DIRECT=1: straight into the pinned host framebuffer instead, RtSphereParams::fb_global_rows -
+//     2 % less wall time on a 11 ms frame, every store its own bus write).  The tile kernel (variant 1) transposes its 8x8 tile through LDS so that a
+//     wave writes row-contiguous dwords;
 //   * parameters needed once per sample (camera, image size) are re-read from a device copy of the parameter block (RtSphereParams::self);
 //   * the scene copy of a workgroup comes in three forms (stage_scene, template parameter SCENE): everything in the LDS; the test data in the LDS and the
 //     hit data in global memory (two workgroups per CU up to ~1500 spheres, LDS-resident up to ~5000); everything read from global memory beyond that.

@@ -105,7 +105,7 @@ struct RtSphereParams {
                                 // row << 16 | column, rays, 0, 0) at ord_rec[2 pos], [2 pos + 1]: one sector per pixel written and read, not three.  (Measured and dropped:
                                 // 24-byte records as three 8-byte pieces - 8 MB less per frame, the frame 4 % slower.)
     int32_t xcd_queues;         // 8: one set of cost lists and queue counters per XCD (P.queue + 64 x, kXcdQueueWords); a pixel belongs to the XCD
-                                // ((local row * nx + column) >> 5) & 7, so the 32 pixels of three adjacent 128-byte framebuffer lines are finished by waves behind ONE
+                                // rt_xcd_of_pixel(local row, nx, column) - a hash of (local row * nx + column) >> 5 -, so the 32 pixels of three adjacent 128-byte framebuffer lines are finished by waves behind ONE
                                 // L2, which merges their 12-byte stores into whole lines (`fb` in device memory).  0 / 1: one queue for the machine
     int32_t p1_tile_major;      // 1: the first dispatch hands out its two-sample items in tile-major order (a wave parks the pixels of two adjacent 8x8 tiles: its 16-byte
                                 // states fill whole lines) instead of scattered
@@ -113,7 +113,14 @@ struct RtSphereParams {
 constexpr int kXcdQueueWords = 64;      // words per queue block: [0] general counter [1] chain counter [2] middle-tier counter [3] first position of this XCD's lists in
                                         // `order` [4 .. 4 + 18) list lengths [22 .. 22 + 18) fill cursors
 constexpr int kXcdQueues = 8;
-__host__ __device__ inline uint32_t rt_xcd_of_pixel(uint32_t local_row, uint32_t nx, uint32_t column) { return ((local_row * nx + column) >> 5) & 7u; }
+// (the unit index hashed, not its low bits: an image 256 k pixels wide - 3840 - would give every XCD the same columns of every row)
+__host__ __device__ inline uint32_t rt_xcd_of_pixel(uint32_t local_row, uint32_t nx, uint32_t column) {
+#ifdef RT_XCD_PLAIN
+    return ((local_row * nx + column) >> 5) & 7u;
+#else
+    return ((((local_row * nx + column) >> 5) * 2654435761u) >> 29) & 7u;
+#endif
+}
 
 struct RtMeshParams {
     rt_camera cam;
@@ -159,6 +166,10 @@ struct RtMeshParams {
     uint32_t* order;            // queue position -> (local row << 16 | column)
     float4* ord_state;          // the parked state in queue order
     uint32_t* ord_rays;
+    // the traffic forms of the two-dispatch frame, as in RtSphereParams (ord_rec, xcd_queues; p1_segments = its p1_tile_major == 2)
+    float4* ord_rec;
+    int32_t xcd_queues;
+    int32_t p1_segments;
 };
 
 // LDS the sphere kernel needs for a scene of n spheres (n_padded slots).

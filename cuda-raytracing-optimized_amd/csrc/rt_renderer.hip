@@ -249,7 +249,7 @@ void setup_devices() {
                 HIP_CHECK(hipMalloc((void**)&d.d_px_rays, d.fb_rows * c.nx * sizeof(uint32_t)));
                 HIP_CHECK(hipMalloc((void**)&d.d_ord_state, padded * sizeof(float4)));
                 HIP_CHECK(hipMalloc((void**)&d.d_ord_rays, padded * sizeof(uint32_t)));
-                if (c.is_spheres) HIP_CHECK(hipMalloc((void**)&d.d_ord_rec, padded * 2 * sizeof(float4)));
+                HIP_CHECK(hipMalloc((void**)&d.d_ord_rec, padded * 2 * sizeof(float4)));
             }
         }
         HIP_CHECK(hipMalloc((void**)&d.d_counters, sizeof(RtCounters)));
@@ -778,6 +778,10 @@ void runRenderer(int ns, int tx, int ty) {
             p.counters = c.opt.counters ? d.d_counters : nullptr;
             p.queue = d.d_queue;
             p.s_split = 0; p.px_state = d.d_px_state; p.px_rays = d.d_px_rays; p.order = d.d_order; p.ord_state = d.d_ord_state; p.ord_rays = d.d_ord_rays;
+            // the traffic forms of the two-dispatch frame, as for sphere scenes (the same switches; the mesh frame always renders into the device framebuffer)
+            p.ord_rec = env_flag("RT_ORD_PACKED", kDefaultOrdPacked) ? d.d_ord_rec : nullptr;
+            p.xcd_queues = env_flag("RT_XCD_QUEUES", kDefaultXcdQueues) ? kXcdQueues : 0;
+            p.p1_segments = (getenv("RT_P1_TILE") ? atoi(getenv("RT_P1_TILE")) : kDefaultP1Tile) == 2 ? 1 : 0;
             if (getenv("RT_WAVE_DEBUG")) {                           // diagnostics: phase cycle / lane counters -> file
                 const size_t dbg_bytes = (size_t)65536 * 8 * sizeof(unsigned long long);
                 if (!d.d_wave_dbg) HIP_CHECK(hipMalloc((void**)&d.d_wave_dbg, dbg_bytes));

@@ -343,6 +343,40 @@ def test_two_dispatch_cost_ordered_mesh_frame_bit_exact(rt, O, stair, textured):
     rt.cleanupRenderer()
 
 
+def test_traffic_forms_of_the_two_dispatch_mesh_frame_bit_exact(rt, O, stair, monkeypatch):
+    """The traffic forms of the two-dispatch frame in the mesh kernel (32-byte parked records, one set of cost lists and queue counters per XCD with the
+    other XCDs' waves taking what a queue has left - chain pixels too -, a first dispatch that scatters 8-pixel row segments): the legacy form, each alone, all together
+    (the default) - the oracle's bits, also with every pixel forced through the chain lists (1 and 6 per wave) on a frame of a few workgroups (most XCDs have no wave:
+    their queues are emptied by the others alone), and for three stripe members."""
+    hm, mats = stair
+    nx, ny, ns = 88, 72, 16
+    cam = rt.staircase_camera(nx, ny)
+    ref, _ = O.render(O.mesh_scene(hm, mats), cam, O.default_options(False), nx, ny, ns, 24)
+    off = {"RT_ORD_PACKED": "0", "RT_XCD_QUEUES": "0", "RT_P1_TILE": "0"}
+    combos = [{}, {"RT_ORD_PACKED": "1"}, {"RT_XCD_QUEUES": "1"}, {"RT_P1_TILE": "2"}, {"RT_ORD_PACKED": "1", "RT_XCD_QUEUES": "1", "RT_P1_TILE": "2"}]
+    ks, keep = rt.make_kernel_scene(hm, mats)
+    fb = rt.initRenderer(ks, cam, nx, ny, 24, keepalive=keep)
+    o = rt.getDefaultRenderOptions(False)
+    for combo in combos:
+        for n in off:
+            monkeypatch.setenv(n, combo.get(n, off[n]))
+        for thr, lanes, frac in ((448, 3, 8), (17, 1, 0), (17, 6, 0)):
+            monkeypatch.setenv("RT_MESH_CHAIN_THR", str(thr)); monkeypatch.setenv("RT_MESH_CHAIN_LANES", str(lanes)); monkeypatch.setenv("RT_MESH_CHAIN_FRAC", str(frac))
+            rt.setRenderOptions(o, part_rank=0, part_world=1, stripe_rows=8)
+            for frame in range(2):
+                fb[:] = 0
+                rt.runRenderer(ns, 8, 8)
+                got = np.array(fb, copy=True)
+                assert not np.isnan(got).any(), (combo, thr, lanes, frame)
+                assert np.array_equal(_bits(got), _bits(ref)), (combo, thr, lanes, frame, np.count_nonzero(_bits(got) != _bits(ref)))
+        fb[:] = 0
+        for r in range(3):
+            rt.setRenderOptions(o, part_rank=r, part_world=3, stripe_rows=8)
+            rt.runRenderer(ns, 8, 8)
+        assert np.array_equal(_bits(np.array(fb)), _bits(ref)), (combo, "stripes")
+    rt.cleanupRenderer()
+
+
 def test_full_size_c4_frame_two_dispatches_with_chain_waves_equals_single_dispatch(rt):
     """BASELINE config C4's scene and frame (detail-4 staircase, 1920x1080, depth 64, NEE + RR) at 16 spp: the production frame - two dispatches, cost
     order, expensive lists spread, the ~0.1 % most expensive pixels in chain waves with their real list-0 threshold - against the single scattered dispatch

@@ -1,3 +1,5 @@
+"""tools/repro_lost_pixels.py - 96x64x10spp three times over (init, two frames, cleanup): NaN pixels per frame and differences between the images.  The frame of six
+workgroups that showed the chain pixel of an XCD without waves being lost (RT_XCD_QUEUES=1 before the leftovers rule); RT_CLEANUP_DEVICE_RESET=1 adds the reset."""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cuda_raytracing_optimized_amd as rt
