@@ -39,6 +39,10 @@ print("distinct CUs used:", len(uk), "waves per CU: min %d max %d" % (cnt.min(),
 for c in sorted(set(cnt)):
     sel = np.isin(key, uk[cnt == c])
     print("  CUs with %2d waves: %4d waves, median end %.1f ms, median exhausted %.1f" % (c, sel.sum(), np.median(end[sel]), np.nanmedian(tex[sel]) if np.isfinite(tex[sel]).any() else -1))
+print("per XCD (XCC_ID): waves, the moment a wave first found every queue empty (median), end of its waves (median / max) - one work queue per XCD since round 4:")
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print("  XCD %d: %4d waves, exhausted %.2f ms, end median %.2f max %.2f" % (x, m.sum(), np.nanmedian(tex[m]) if np.isfinite(tex[m]).any() else -1, np.median(end[m]), end[m].max()))
 
 if sec.sum() > 0:
     names = ["ray set-up (unit dir)", "big spheres", "group boxes + pair list", "pair rounds (phase 1)", "candidates (exact tail)", "shade", "sparse scan", "refill / start pixel+sample"]
